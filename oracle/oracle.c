@@ -1,0 +1,452 @@
+/*
+ * oracle.c -- CPU restatement of the reference hot path.  TEST INFRASTRUCTURE ONLY; see
+ * oracle.h for the rules on who may load this and for the parity status of each part.
+ * Citations are file:line inside /root/reference.
+ */
+#include "oracle.h"
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------ conversion half */
+
+/* sparse_matrix.c:471-513.  freq = per-row count (:485-487), jmp = exclusive scan
+ * (:489-491), then one in-order pass that places entry i at jmp[r]+inc[r] (:506-513).
+ * In-order placement is what makes the sort stable. */
+void orc_sort_coo_row(uint32_t nnz, uint32_t nrows, const int *rows, const int *cols,
+                      const double *vals, int *s_rows, int *s_cols, double *s_vals) {
+  if (nrows == 0) return;
+  int *freq = (int *)calloc(nrows, sizeof(int));
+  int *inc = (int *)calloc(nrows, sizeof(int));
+  int *jmp = (int *)malloc(sizeof(int) * nrows);
+  for (uint32_t i = 0; i < nnz; i++) freq[rows[i]]++;
+  jmp[0] = 0;
+  for (uint32_t i = 1; i < nrows; i++) jmp[i] = jmp[i - 1] + freq[i - 1];
+  for (uint32_t i = 0; i < nnz; i++) {
+    int r = rows[i];
+    int p = jmp[r] + inc[r];
+    s_vals[p] = vals[i];
+    s_rows[p] = r;
+    s_cols[p] = cols[i];
+    inc[r]++;
+  }
+  free(freq);
+  free(inc);
+  free(jmp);
+}
+
+/* sparse_matrix.c:649-700.  Pass 1 histogram (:664-665), pass 2 exclusive scan with an
+ * unsigned running sum (:669-674), pass 3 scatter using row_pointers as cursor (:684-693),
+ * pass 4 shift right by one (:696-700).  Defect Q7 (unsigned loop for nrows==0) is
+ * guarded instead of reproduced. */
+void orc_coo_to_csr(uint32_t nnz, uint32_t nrows, const int *rows, const int *cols,
+                    const double *vals, int *row_pointers, int *column_indices,
+                    double *values) {
+  memset(row_pointers, 0, ((size_t)nrows + 1) * sizeof(int));
+  for (uint32_t i = 0; i < nnz; i++) row_pointers[rows[i]]++;
+  unsigned int cum_sum = 0;
+  for (uint32_t i = 0; i < nrows; i++) {
+    unsigned int row_nnz = (unsigned int)row_pointers[i];
+    row_pointers[i] = (int)cum_sum;
+    cum_sum += row_nnz;
+  }
+  for (uint32_t i = 0; i < nnz; i++) {
+    unsigned int r = (unsigned int)rows[i];
+    unsigned int j = (unsigned int)row_pointers[r];
+    column_indices[j] = cols[i];
+    values[j] = vals[i];
+    row_pointers[r]++;
+  }
+  if (nrows > 0)
+    for (uint32_t i = nrows - 1; i > 0; i--) row_pointers[i] = row_pointers[i - 1];
+  row_pointers[0] = 0;
+  row_pointers[nrows] = (int)nnz;
+}
+
+/* solvers.c:214-231.  The reference walks the sorted COO: start at nnz/np, advance to the
+ * end of the row that index falls in (:219-222), record it (:224), step by nnz/np again
+ * (:227), force the last part to the end (:230).  Restated on the row-pointer array with
+ * an exclusive end (fixes Q1), no read past the end (Q3), no rowindx[-1] (Q2), 64-bit
+ * offsets (Q4).  Rows without entries that sit between two parts go to the earlier part,
+ * so every row has exactly one owner (the reference leaves them ownerless, :272-276). */
+void orc_partition_rows(uint32_t nrows, const int64_t *rowptr, int np, int64_t *row_start) {
+  const int64_t nnz = rowptr[nrows];
+  const int64_t local_chunk = nnz / np;
+  int64_t chunk = local_chunk;
+  row_start[0] = 0;
+  for (int i = 0; i < np; i++) {
+    int64_t end_row; /* exclusive row end of part i */
+    if (i == np - 1 || chunk >= nnz) {
+      end_row = nrows;
+    } else {
+      /* row containing nnz index `chunk`: largest r with rowptr[r] <= chunk */
+      int64_t lo = 0, hi = nrows;
+      while (hi - lo > 1) {
+        int64_t mid = (lo + hi) / 2;
+        if (rowptr[mid] <= chunk) lo = mid; else hi = mid;
+      }
+      end_row = lo + 1;
+      chunk = rowptr[end_row]; /* first entry after that row */
+      /* rows with no entries directly after it stay with this part */
+      while (end_row < nrows && rowptr[end_row + 1] == rowptr[end_row]) end_row++;
+    }
+    if (end_row < row_start[i]) end_row = row_start[i];
+    row_start[i + 1] = end_row;
+    chunk += local_chunk;
+  }
+  row_start[np] = nrows;
+}
+
+/* ------------------------------------------------------------------------- SpMV */
+
+/* test/sblas_mv_rd.c:55-69: y[row] starts at 0 and receives a[i]*x[col[i]] in storage
+ * order.  alpha/beta follow hypre_ParCSRMatrixMatvec's contract y = alpha*A*x + beta*y
+ * as it is called for PCG (alpha=1,beta=0 and alpha=-1,beta=1). */
+static inline double row_dot(const int *col, const double *val, const double *x, int b, int e) {
+  double t = 0.0;
+  for (int j = b; j < e; j++) t += val[j] * x[col[j]];
+  return t;
+}
+
+void orc_csr_spmv(uint32_t nrows, const int *rowptr, const int *col, const double *val,
+                  double alpha, const double *x, double beta, double *y) {
+  for (uint32_t i = 0; i < nrows; i++) {
+    double t = row_dot(col, val, x, rowptr[i], rowptr[i + 1]);
+    y[i] = (beta == 0.0) ? alpha * t : alpha * t + beta * y[i];
+  }
+}
+
+void orc_csr_spmv_omp(uint32_t nrows, const int *rowptr, const int *col, const double *val,
+                      double alpha, const double *x, double beta, double *y) {
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < (int64_t)nrows; i++) {
+    double t = row_dot(col, val, x, rowptr[i], rowptr[i + 1]);
+    y[i] = (beta == 0.0) ? alpha * t : alpha * t + beta * y[i];
+  }
+}
+
+void orc_csr_diag(uint32_t nrows, const int *rowptr, const int *col, const double *val,
+                  double *diag) {
+  for (uint32_t i = 0; i < nrows; i++) {
+    double d = 0.0;
+    for (int j = rowptr[i]; j < rowptr[i + 1]; j++)
+      if ((uint32_t)col[j] == i) { d = val[j]; break; }
+    diag[i] = d;
+  }
+}
+
+/* --------------------------------------------------------------------- vector ops */
+
+static double v_dot(uint32_t n, const double *a, const double *b, int omp) {
+  double s = 0.0;
+  if (omp) {
+#pragma omp parallel for reduction(+ : s) schedule(static)
+    for (int64_t i = 0; i < (int64_t)n; i++) s += a[i] * b[i];
+  } else {
+    for (uint32_t i = 0; i < n; i++) s += a[i] * b[i];
+  }
+  return s;
+}
+static void v_axpy(uint32_t n, double a, const double *x, double *y, int omp) {
+  if (omp) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < (int64_t)n; i++) y[i] += a * x[i];
+  } else {
+    for (uint32_t i = 0; i < n; i++) y[i] += a * x[i];
+  }
+}
+static void v_precond(uint32_t n, int precond, const double *dinv, const double *r, double *z,
+                      int omp) {
+  /* identity: hypre_ParKrylovIdentity copies r; diag scale: HYPRE_ParCSRDiagScale
+   * divides by the diagonal (x = y ./ diag(A)) */
+  if (omp) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < (int64_t)n; i++) z[i] = precond ? r[i] * dinv[i] : r[i];
+  } else {
+    for (uint32_t i = 0; i < n; i++) z[i] = precond ? r[i] * dinv[i] : r[i];
+  }
+}
+static void spmv(uint32_t n, const int *rp, const int *c, const double *v, double alpha,
+                 const double *x, double beta, double *y, int omp) {
+  if (omp) orc_csr_spmv_omp(n, rp, c, v, alpha, x, beta, y);
+  else orc_csr_spmv(n, rp, c, v, alpha, x, beta, y);
+}
+
+/* ---------------------------------------------------------------------------- PCG */
+
+/* Restatement of hypre_PCGSolve (HYPRE krylov/pcg.c, upstream; not in /root/reference)
+ * under the settings the reference applies at solvers.c:732-744:
+ *   MaxIter=maxit (:732), Tol=tol (:734), TwoNorm=1 (:735), RelChange=1 (:737),
+ *   Logging=1 (:744); a_tol=0, rtol=0, cf_tol=0, stop_crit=0, recompute_residual=0.
+ * Steps, in upstream order:
+ *   bi_prod = <b,b> (two_norm) or <C b,b>;  eps = tol^2;
+ *   bi_prod == 0  ->  x = b (= 0), 0 iterations, norm 0;
+ *   r = b - A x;  p = C r;  gamma = <r,p>;
+ *   loop i=1..maxit:
+ *     s = A p;  sdotp = <s,p>;  sdotp==0 -> break;  alpha = gamma/sdotp;
+ *     !(alpha > DBL_MIN) -> break;  gamma_old = gamma;
+ *     x += alpha p;  r -= alpha s;  s = C r;  gamma = <r,s>;
+ *     i_prod = <r,r> (two_norm) or gamma;
+ *     converged if i_prod/bi_prod < eps, and with rel_change (only while i_prod > 0)
+ *       additionally alpha^2 <p,p>/<x,x> < eps;   converged -> break;
+ *     |gamma| < DBL_MIN -> break;
+ *     beta = gamma/gamma_old;  p = s + beta p  (scale p, then add s).
+ *   rel_res_norm = sqrt(i_prod/bi_prod).
+ * PARITY UNPINNED: nothing in /root/reference fixes these results. */
+void orc_pcg(uint32_t n, const int *rowptr, const int *col, const double *val,
+             const double *b, double *x, int precond, double tol, int maxit,
+             int two_norm, int rel_change, int use_omp, orc_solve_info *info,
+             double *rel_norms) {
+  double *r = (double *)malloc(sizeof(double) * n);
+  double *p = (double *)malloc(sizeof(double) * n);
+  double *s = (double *)malloc(sizeof(double) * n);
+  double *dinv = NULL;
+  if (precond) {
+    dinv = (double *)malloc(sizeof(double) * n);
+    orc_csr_diag(n, rowptr, col, val, dinv);
+    for (uint32_t i = 0; i < n; i++) dinv[i] = 1.0 / dinv[i];
+  }
+  info->iterations = 0;
+  info->converged = 0;
+  info->breakdown = 0;
+  info->rel_res_norm = 0.0;
+
+  double bi_prod;
+  if (two_norm) {
+    bi_prod = v_dot(n, b, b, use_omp);
+  } else {
+    v_precond(n, precond, dinv, b, p, use_omp);
+    bi_prod = v_dot(n, p, b, use_omp);
+  }
+  const double eps = tol * tol;
+  if (!(bi_prod > 0.0)) {
+    memcpy(x, b, sizeof(double) * n);
+    if (rel_norms) rel_norms[0] = 0.0;
+    goto done;
+  }
+  /* r = b - A x */
+  memcpy(r, b, sizeof(double) * n);
+  spmv(n, rowptr, col, val, -1.0, x, 1.0, r, use_omp);
+  v_precond(n, precond, dinv, r, p, use_omp);
+  double gamma = v_dot(n, r, p, use_omp);
+  double i_prod = two_norm ? v_dot(n, r, r, use_omp) : gamma;
+  const double i_prod_0 = i_prod;
+  if (rel_norms) rel_norms[0] = sqrt(i_prod / bi_prod);
+
+  long long i = 0;
+  while (i + 1 <= maxit) {
+    i++;
+    spmv(n, rowptr, col, val, 1.0, p, 0.0, s, use_omp);
+    double sdotp = v_dot(n, s, p, use_omp);
+    if (sdotp == 0.0) {
+      info->breakdown = 1;
+      if (i == 1) i_prod = i_prod_0;
+      break;
+    }
+    double alpha = gamma / sdotp;
+    if (!(alpha > DBL_MIN)) {
+      info->breakdown = 2;
+      if (i == 1) i_prod = i_prod_0;
+      break;
+    }
+    double gamma_old = gamma;
+    v_axpy(n, alpha, p, x, use_omp);
+    v_axpy(n, -alpha, s, r, use_omp);
+    v_precond(n, precond, dinv, r, s, use_omp);
+    gamma = v_dot(n, r, s, use_omp);
+    i_prod = two_norm ? v_dot(n, r, r, use_omp) : gamma;
+    if (rel_norms) rel_norms[i] = sqrt(i_prod / bi_prod);
+
+    int tentatively_converged = (i_prod / bi_prod < eps);
+    if (tentatively_converged && rel_change && i_prod > 0.0) {
+      double pi_prod = v_dot(n, p, p, use_omp);
+      double xi_prod = v_dot(n, x, x, use_omp);
+      double ratio = alpha * alpha * pi_prod / xi_prod;
+      if (ratio >= eps) tentatively_converged = 0;
+    }
+    if (tentatively_converged) {
+      info->converged = 1;
+      break;
+    }
+    if (gamma < DBL_MIN && -gamma < DBL_MIN) {
+      info->breakdown = 3;
+      break;
+    }
+    double beta = gamma / gamma_old;
+    /* p = s + beta p: ScaleVector(beta,p) then Axpy(1.0,s,p) */
+    if (use_omp) {
+#pragma omp parallel for schedule(static)
+      for (int64_t k = 0; k < (int64_t)n; k++) p[k] = beta * p[k] + s[k];
+    } else {
+      for (uint32_t k = 0; k < n; k++) p[k] = beta * p[k] + s[k];
+    }
+  }
+  info->iterations = i;
+  info->rel_res_norm = sqrt(i_prod / bi_prod);
+done:
+  free(r);
+  free(p);
+  free(s);
+  free(dinv);
+}
+
+/* ------------------------------------------------------------------------- Jacobi */
+
+/* Extension: the reference has no Jacobi iteration.  Definition:
+ * x_{k+1} = x_k + D^-1 (b - A x_k), the diagonal taken from the row itself.  The
+ * residual of x_k falls out of the same pass; it is tested when k % check_every == 0
+ * (before the update is applied), so `iterations` = number of updates applied. */
+void orc_jacobi(uint32_t n, const int *rowptr, const int *col, const double *val,
+                const double *b, double *x, double tol, int maxit, int check_every,
+                int use_omp, orc_solve_info *info) {
+  double *xn = (double *)malloc(sizeof(double) * n);
+  double *cur = x, *nxt = xn;
+  const double bb = v_dot(n, b, b, use_omp);
+  info->iterations = 0;
+  info->converged = 0;
+  info->breakdown = 0;
+  info->rel_res_norm = 0.0;
+  if (check_every < 1) check_every = 1;
+  if (!(bb > 0.0)) {
+    memcpy(x, b, sizeof(double) * n);
+    free(xn);
+    return;
+  }
+  long long k = 0;
+  for (;;) {
+    double rr = 0.0;
+    if (use_omp) {
+#pragma omp parallel for reduction(+ : rr) schedule(static)
+      for (int64_t i = 0; i < (int64_t)n; i++) {
+        double t = 0.0, d = 0.0;
+        for (int j = rowptr[i]; j < rowptr[i + 1]; j++) {
+          t += val[j] * cur[col[j]];
+          if (col[j] == i) d = val[j];
+        }
+        double res = b[i] - t;
+        rr += res * res;
+        nxt[i] = cur[i] + res / d;
+      }
+    } else {
+      for (uint32_t i = 0; i < n; i++) {
+        double t = 0.0, d = 0.0;
+        for (int j = rowptr[i]; j < rowptr[i + 1]; j++) {
+          t += val[j] * cur[col[j]];
+          if ((uint32_t)col[j] == i) d = val[j];
+        }
+        double res = b[i] - t;
+        rr += res * res;
+        nxt[i] = cur[i] + res / d;
+      }
+    }
+    /* rr is the residual of `cur` (iteration k) */
+    if (k % check_every == 0 || k >= maxit) {
+      info->rel_res_norm = sqrt(rr / bb);
+      if (rr / bb < tol * tol) { info->converged = 1; break; }
+    }
+    if (k >= maxit) break;
+    double *t = cur; cur = nxt; nxt = t;
+    k++;
+  }
+  info->iterations = k;
+  if (cur != x) memcpy(x, cur, sizeof(double) * n);
+  free(xn);
+}
+
+/* --------------------------------------------------------------------- generators */
+
+uint64_t orc_splitmix64(uint64_t x) {
+  uint64_t z = x + 0x9E3779B97F4A7C15ULL;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  return z ^ (z >> 31);
+}
+
+/* Edge e draws from words w_k = splitmix64(base + k), base = splitmix64(seed ^ e*C).
+ * Level l (most significant bit first) uses the 16-bit field (l%4) of word l/4 against
+ * thresholds floor(a*65536), +b, +c: quadrants (0,0) (0,1) (1,0) (1,1) as (row bit, col
+ * bit).  Value = uniform(-1,1) from word 15.  Duplicates are kept, as the reference's
+ * loader keeps them (sparse_matrix.c:349-357). */
+void orc_rmat_coo(int scale, uint64_t nedges, uint64_t seed, double a, double b, double c,
+                  int *rows, int *cols, double *vals) {
+  const uint32_t ta = (uint32_t)(a * 65536.0);
+  const uint32_t tb = ta + (uint32_t)(b * 65536.0);
+  const uint32_t tc = tb + (uint32_t)(c * 65536.0);
+#pragma omp parallel for schedule(static)
+  for (int64_t e = 0; e < (int64_t)nedges; e++) {
+    const uint64_t base = orc_splitmix64(seed ^ ((uint64_t)e * 0xD1B54A32D192ED03ULL));
+    uint32_t r = 0, cc = 0;
+    uint64_t w = 0;
+    for (int l = 0; l < scale; l++) {
+      if ((l & 3) == 0) w = orc_splitmix64(base + (uint64_t)(l >> 2));
+      uint32_t u = (uint32_t)(w >> (16 * (l & 3))) & 0xFFFFu;
+      uint32_t rb = (u >= tb), cb = (u >= ta && u < tb) || (u >= tc);
+      r = (r << 1) | rb;
+      cc = (cc << 1) | cb;
+    }
+    const uint64_t wv = orc_splitmix64(base + 15);
+    rows[e] = (int)r;
+    cols[e] = (int)cc;
+    vals[e] = (double)(wv >> 11) * (1.0 / 9007199254740992.0) * 2.0 - 1.0;
+  }
+}
+
+int64_t orc_stencil_csr(int kind, int nx, int ny, int nz, int *rowptr, int *col, double *val) {
+  if (kind == 5) nz = 1;
+  const int64_t n = (int64_t)nx * ny * nz;
+  int64_t k = 0;
+  for (int64_t row = 0; row < n; row++) {
+    const int ix = (int)(row % nx), iy = (int)((row / nx) % ny), iz = (int)(row / ((int64_t)nx * ny));
+    if (rowptr) rowptr[row] = (int)k;
+    if (kind == 27) {
+      for (int dz = -1; dz <= 1; dz++)
+        for (int dy = -1; dy <= 1; dy++)
+          for (int dx = -1; dx <= 1; dx++) {
+            int x = ix + dx, y = iy + dy, z = iz + dz;
+            if (x < 0 || x >= nx || y < 0 || y >= ny || z < 0 || z >= nz) continue;
+            if (col) {
+              col[k] = (int)(((int64_t)z * ny + y) * nx + x);
+              val[k] = (dx == 0 && dy == 0 && dz == 0) ? 26.0 : -1.0;
+            }
+            k++;
+          }
+    } else {
+      const double diag = (kind == 5) ? 4.0 : 6.0;
+      /* ascending column order: z-1, y-1, x-1, self, x+1, y+1, z+1 */
+      const int off[7][3] = {{0, 0, -1}, {0, -1, 0}, {-1, 0, 0}, {0, 0, 0}, {1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+      for (int t = 0; t < 7; t++) {
+        if (kind == 5 && off[t][2] != 0) continue;
+        int x = ix + off[t][0], y = iy + off[t][1], z = iz + off[t][2];
+        if (x < 0 || x >= nx || y < 0 || y >= ny || z < 0 || z >= nz) continue;
+        if (col) {
+          col[k] = (int)(((int64_t)z * ny + y) * nx + x);
+          val[k] = (t == 3) ? diag : -1.0;
+        }
+        k++;
+      }
+    }
+  }
+  if (rowptr) rowptr[n] = (int)k;
+  return k;
+}
+
+int64_t orc_banded_csr(int64_t n, int hb, int *rowptr, int *col, double *val) {
+  int64_t k = 0;
+  for (int64_t row = 0; row < n; row++) {
+    if (rowptr) rowptr[row] = (int)k;
+    for (int64_t c = row - hb; c <= row + hb; c++) {
+      if (c < 0 || c >= n) continue;
+      if (col) {
+        col[k] = (int)c;
+        val[k] = (c == row) ? (double)(2 * hb + 1) : -1.0;
+      }
+      k++;
+    }
+  }
+  if (rowptr) rowptr[n] = (int)k;
+  return k;
+}
