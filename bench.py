@@ -1,0 +1,146 @@
+#!/usr/bin/env python3
+"""bench.py -- CG iterations/s and SpMV effective HBM GB/s on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
+
+One "step" = one CG iteration (K1 SpMV+dots, K2 x/r update+dots, K3 direction update).
+Default workload at N=1 is BASELINE.json configs[1]: 3D 7-point Laplacian 256^3
+(16.7M rows), Jacobi-preconditioned CG, fp64, matrix generated in HBM (synthetic).
+Prints ONE JSON line (rank 0).  The timed region starts with everything resident in HBM.
+
+For N>1 the driver starts one rank per GPU through torch.distributed.run; torch is used
+for the rendezvous/barrier only, the solve runs inside libmi355_krylov.so.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+WORKLOADS = {
+    # name: (kind, nx, ny, nz, precond, description)
+    "lap7_256_jacobi_pcg": (7, 256, 256, 256, 1, "3D 7-pt Laplacian 256^3, Jacobi-preconditioned CG, fp64"),
+    "lap7_512_cg": (7, 512, 512, 512, 0, "3D 7-pt Laplacian 512^3, CG, fp64 (north-star scaling target)"),
+    "poisson5_1024_cg": (5, 1024, 1024, 1, 0, "2D 5-pt Poisson 1024^2, CG, fp64"),
+    "lap27_256_cg": (27, 256, 256, 256, 0, "3D 27-pt stencil 256^3, CG, fp64"),
+}
+
+
+def cpu_baseline(kind, nx, ny, nz, precond, iters):
+    """the oracle's OpenMP CG on the host cores, bounded sample of the same workload"""
+    import oracle
+    t0 = time.time()
+    rp, ci, v = oracle.stencil_csr(kind, nx, ny, nz)
+    n = rp.size - 1
+    b = np.ones(n)
+    oracle.pcg(rp, ci, v, b, precond=precond, tol=0.0, maxit=2, omp=True)   # page-in / warm-up
+    t1 = time.time()
+    o = oracle.pcg(rp, ci, v, b, precond=precond, tol=0.0, maxit=iters, omp=True)
+    dt = time.time() - t1
+    cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+    return {"value": round(o["iterations"] / dt, 3), "unit": "CG iterations/s", "cores": cores, "kind": "port",
+            "sample": f"{iters} CG iterations of the same system (oracle/oracle.c orc_pcg, OpenMP, "
+                      f"setup {t1 - t0:.1f}s excluded)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--workload", default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-iters", type=int, default=20)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch through torch.distributed.run")
+
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(local_rank)
+
+    import iterative_solvers_amd as mk
+    mk.init(local_rank)
+
+    if world > 1:
+        from iterative_solvers_amd import distributed as mkd
+        return mkd.bench_main(args, rank, local_rank, world)
+
+    name = args.workload or "lap7_256_jacobi_pcg"
+    kind, nx, ny, nz, precond, desc = WORKLOADS[name]
+    A = mk.Matrix.stencil(kind, nx, ny, nz)
+    n, nnz = A.nrows, A.nnz
+    info = A.info()
+    b, x = mk.Vector(n, fill=1.0), mk.Vector(n, fill=0.0)
+
+    def run(iters):
+        S = mk.PCG(max_iter=iters, tol=0.0, two_norm=1, rel_change=1, precond=precond, logging=0, check_every=50)
+        S.setup(A, b, x)
+        x.fill(0.0)
+        mk.synchronize()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = S.solve(A, b, x)           # returns after the final read-back (stream drained)
+        mk.synchronize()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        assert res["iterations"] == iters, res
+        return dt, res
+
+    run(max(args.warmup, 1))
+    dt, res = run(args.steps)
+    ms_per_step = dt * 1e3 / args.steps
+    iters_per_s = args.steps / dt
+
+    # dominant kernel: the fused SpMV (+<s,p>,<p,p>) launch, timed alone with HIP events on
+    # the library's own stream
+    s = mk.Vector(n)
+    reps = 50
+    for _ in range(5):
+        A.spmv_dot(b, s, want=False)
+    mk.timer_start()
+    for _ in range(reps):
+        A.spmv_dot(b, s, want=False)
+    spmv_ms = mk.timer_stop() / reps
+    spmv_bytes = 12 * nnz + 20 * n + 4          # val 8 + col 4 per entry, rowptr 4 + x 8 + y 8 per row
+    achieved = spmv_bytes / (spmv_ms * 1e-3) / 1e9
+    iter_bytes = 12 * nnz + (108 if precond else 92) * n
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        traffic = json.load(open(tpath)).get(name)
+
+    out = {
+        "metric": "CG iterations/s (fp64, fused SpMV+dot+axpy) with SpMV effective HBM GB/s",
+        "value": round(iters_per_s, 2), "unit": "CG iterations/s", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": desc, "name": name, "rows": n, "nnz": nnz, "precond": "jacobi" if precond else "none",
+                   "spmv_kernel": "vector" if info.kernel == 1 else "stream", "lanes_per_row": info.lanes_per_row,
+                   "parallelism": "1 GPU"},
+        "iteration_effective_GBps": round(iter_bytes / (ms_per_step * 1e-3) / 1e9, 1),
+        "roofline": {"bound": "hbm", "kernel": "spmv+dot (K1)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                     "bytes_per_launch": spmv_bytes, "avg_launch_ms": round(spmv_ms, 5)},
+        "final_rel_res_norm": res["rel_res_norm"],
+    }
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(kind, nx, ny, nz, precond, args.cpu_iters)
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,183 @@
+/*
+ * mk_krylov.h -- C ABI of libmi355_krylov.so: the MI355X (gfx950) SpMV + Krylov hot path.
+ *
+ * This is the drop-in boundary.  The reference (eemorsi/iterative_solvers) has no plugin
+ * interface; what its driver src/solvers.c does for solver id 50 is a fixed sequence of
+ * HYPRE calls.  Every entry point below names the reference call site (file:line in
+ * /root/reference) it stands in for.  INTEGRATION.md shows the patched solvers.c.
+ *
+ * Conventions
+ *   - plain C, opaque handles, no C++/torch types;
+ *   - every function returns 0 on success or a negative mk_status; the text of the last
+ *     failure is available from mk_last_error_string().  The library never calls exit()
+ *     (the reference's loader does: sparse_matrix.c:43-66);
+ *   - host pointers are copied during the call and never kept (HYPRE_IJMatrixSetValues
+ *     copies too: the driver frees its COO right after, solvers.c:376-378);
+ *   - one caller thread per process; one GPU per process (one rank per GPU);
+ *   - local indices are int32, global row offsets and global nnz are int64.
+ */
+#ifndef MK_KRYLOV_H
+#define MK_KRYLOV_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Host containers of the reference, field for field (sparse_matrix.h:24-44).  If the
+ * reference's own header was included first its definitions are used. */
+#ifndef SPARSE_MATRIX_H
+#define SPARSE_MATRIX_H
+struct SparseMatrixCSR_STRUCT {
+  double *values;
+  int *column_indices;
+  int *row_pointers;
+  unsigned int nrows;
+  unsigned int ncolumns;
+  unsigned int nnz;
+};
+typedef struct SparseMatrixCSR_STRUCT SparseMatrixCSR;
+struct SparseMatrixCOO_STRUCT {
+  double *values;
+  int *rows;
+  int *columns;
+  unsigned int nrows;
+  unsigned int ncolumns;
+  unsigned int nnz;
+};
+typedef struct SparseMatrixCOO_STRUCT SparseMatrixCOO;
+#endif
+
+typedef enum {
+  MK_OK = 0,
+  MK_ERR_INVALID = -1,      /* bad argument (null, size mismatch, index out of range) */
+  MK_ERR_HIP = -2,          /* a HIP runtime call failed */
+  MK_ERR_NOT_INIT = -3,     /* mk_init() was not called */
+  MK_ERR_NO_DEVICE = -4,    /* no gfx950 device visible */
+  MK_ERR_ALLOC = -5,        /* host or device allocation failed */
+  MK_ERR_COMM = -6,         /* RCCL failure */
+  MK_ERR_UNSUPPORTED = -7
+} mk_status;
+
+typedef struct mk_matrix mk_matrix;   /* stands in for HYPRE_IJMatrix / HYPRE_ParCSRMatrix (solvers.c:55-56) */
+typedef struct mk_vector mk_vector;   /* HYPRE_IJVector / HYPRE_ParVector (solvers.c:57-60) */
+typedef struct mk_coo mk_coo;         /* a COO matrix resident in device memory */
+typedef struct mk_pcg mk_pcg;         /* HYPRE_Solver for PCG (solvers.c:65,729) */
+typedef struct mk_jacobi mk_jacobi;   /* extension: plain Jacobi iteration (no reference counterpart) */
+
+/* ---- life cycle: HYPRE_Init() / HYPRE_Finalize() (solvers.c:79,1560) ------------------- */
+int mk_init(int device_id);
+int mk_finalize(void);
+const char *mk_last_error_string(void);
+/* the hipStream_t every kernel of this library is launched on (for HIP-event timing) */
+void *mk_get_stream(void);
+int mk_synchronize(void);
+/* HIP-event timers on that stream: start, stop, then elapsed (milliseconds, synchronises) */
+int mk_timer_start(void);
+int mk_timer_stop(float *elapsed_ms);
+
+/* ---- COO -> sorted COO / CSR on the device --------------------------------------------- */
+/* sort_coo_row (sparse_matrix.c:419-529, called at solvers.c:198): stable sort by row.
+ * out arrays are allocated with aligned_alloc(64, ...) like the reference's; free() them. */
+int mk_sort_coo_row(const SparseMatrixCOO *coo, SparseMatrixCOO *sorted);
+/* convert_coo_to_csr (sparse_matrix.c:649-742): bit-identical row_pointers, and
+ * column_indices / values in stable-by-row order.  out arrays: aligned_alloc(64, ...). */
+int mk_coo_to_csr(const SparseMatrixCOO *coo, SparseMatrixCSR *csr);
+
+/* ---- matrix assembly: HYPRE_IJMatrixCreate..Assemble..GetObject (solvers.c:289-374) ----- */
+/* whole matrix on this GPU from the host COO the loader produced (sorted or not) */
+int mk_matrix_from_coo(const SparseMatrixCOO *coo, mk_matrix **A);
+int mk_matrix_from_csr(const SparseMatrixCSR *csr, mk_matrix **A);
+int mk_matrix_from_device_coo(mk_coo *coo, mk_matrix **A);  /* consumes coo's buffers */
+int mk_matrix_destroy(mk_matrix *A);                         /* HYPRE_IJMatrixDestroy (solvers.c:1555) */
+/* copy the device CSR back (tests; HYPRE_IJMatrixPrint's role at solvers.c:451) */
+int mk_matrix_get_csr(const mk_matrix *A, SparseMatrixCSR *csr);
+
+typedef struct {
+  int64_t nrows, ncols, nnz;
+  int32_t max_row_len, min_row_len;
+  double mean_row_len;
+  int64_t hist[16];        /* row-length histogram: bucket k holds rows with len in [2^(k-1), 2^k), bucket 0 = empty rows */
+  int32_t kernel;          /* mk_spmv_kernel chosen from the histogram */
+  int32_t lanes_per_row;   /* for the vector kernels */
+  int64_t long_rows;       /* rows routed to the long-row path */
+} mk_matrix_info;
+int mk_matrix_get_info(const mk_matrix *A, mk_matrix_info *info);
+
+typedef enum {
+  MK_SPMV_AUTO = 0,
+  MK_SPMV_VECTOR = 1,      /* 2^k lanes per row, k from the mean row length (k=6: wavefront per row) */
+  MK_SPMV_STREAM = 2       /* LDS-staged nnz-balanced chunks with in-chunk row split, long rows split over blocks */
+} mk_spmv_kernel;
+/* override the selector (lanes_per_row: 0 = keep, else 1..64 power of two) */
+int mk_matrix_set_spmv_kernel(mk_matrix *A, int kernel, int lanes_per_row);
+
+/* ---- synthetic operators generated in device memory (bench.py; no reference counterpart:
+ *      the reference only reads SuiteSparse files, scripts/bench_all_gpu:2) ---------------- */
+/* kind 5: 2D 5-pt (nz ignored), 7: 3D 7-pt, 27: 3D 27-pt; lexicographic, x fastest.
+ * rows [row_begin,row_end) of the global operator, global column ids. */
+int mk_matrix_generate_stencil(int kind, int nx, int ny, int nz, int64_t row_begin, int64_t row_end, mk_matrix **A);
+int mk_matrix_generate_banded(int64_t n, int half_bandwidth, int64_t row_begin, int64_t row_end, mk_matrix **A);
+/* R-MAT edge list, unsorted, duplicates kept (counter-based splitmix64; oracle/oracle.c holds the same definition) */
+int mk_coo_generate_rmat(int scale, uint64_t nedges, uint64_t seed, double a, double b, double c, mk_coo **coo);
+int mk_coo_from_host(const SparseMatrixCOO *coo, mk_coo **out);
+int mk_coo_download(const mk_coo *coo, SparseMatrixCOO *out);
+int mk_coo_destroy(mk_coo *coo);
+
+/* ---- vectors: HYPRE_IJVectorCreate/SetValues/Assemble (solvers.c:382-436) ---------------- */
+int mk_vector_create(int64_t n, mk_vector **v);
+int mk_vector_set(mk_vector *v, const double *host_values);   /* IJVectorSetValues: copy in */
+int mk_vector_fill(mk_vector *v, double value);               /* b = 1 (solvers.c:404-408), x0 = 0 (:420-426) */
+int mk_vector_get(const mk_vector *v, double *host_values);
+int mk_vector_destroy(mk_vector *v);
+int64_t mk_vector_size(const mk_vector *v);
+
+/* ---- SpMV: hypre_ParCSRMatrixMatvec, y = alpha*A*x + beta*y (inside HYPRE; in-repo stand-in
+ *      test/sblas_mv_rd.c:51-69) ----------------------------------------------------------- */
+int mk_spmv(const mk_matrix *A, double alpha, const mk_vector *x, double beta, mk_vector *y);
+/* the fused kernel the CG loop runs: y = A*x together with <y,x> and <x,x>.  With both
+ * outputs NULL the kernel is only enqueued (no read-back, no synchronisation). */
+int mk_spmv_dot(const mk_matrix *A, const mk_vector *x, mk_vector *y, double *ytx, double *xtx);
+
+/* ---- PCG: HYPRE_ParCSRPCG* / HYPRE_PCG* (solvers.c:729-775) ------------------------------ */
+typedef enum { MK_PRECOND_NONE = 0, MK_PRECOND_JACOBI = 1 } mk_precond;
+int mk_pcg_create(mk_pcg **solver);                               /* HYPRE_ParCSRPCGCreate :729 */
+int mk_pcg_set_max_iter(mk_pcg *solver, int max_iter);            /* HYPRE_PCGSetMaxIter :732 */
+int mk_pcg_set_tol(mk_pcg *solver, double tol);                   /* HYPRE_PCGSetTol :734 */
+int mk_pcg_set_two_norm(mk_pcg *solver, int two_norm);            /* HYPRE_PCGSetTwoNorm :735 */
+int mk_pcg_set_rel_change(mk_pcg *solver, int rel_change);        /* HYPRE_PCGSetRelChange :737 */
+int mk_pcg_set_print_level(mk_pcg *solver, int level);            /* HYPRE_PCGSetPrintLevel :742 */
+int mk_pcg_set_logging(mk_pcg *solver, int logging);              /* HYPRE_PCGSetLogging :744 */
+int mk_pcg_set_precond(mk_pcg *solver, int precond);              /* extension id 51: HYPRE_ParCSRDiagScale semantics */
+int mk_pcg_set_check_every(mk_pcg *solver, int iterations);       /* how often the host reads the device-side stop flag */
+int mk_pcg_setup(mk_pcg *solver, const mk_matrix *A, const mk_vector *b, const mk_vector *x);   /* HYPRE_ParCSRPCGSetup :747 */
+int mk_pcg_solve(mk_pcg *solver, const mk_matrix *A, const mk_vector *b, mk_vector *x);         /* HYPRE_ParCSRPCGSolve :754 */
+int mk_pcg_get_num_iterations(const mk_pcg *solver, long long *iterations);                    /* HYPRE_PCGGetNumIterations :765 */
+int mk_pcg_get_final_relative_residual_norm(const mk_pcg *solver, double *norm);               /* :766 */
+int mk_pcg_get_converged(const mk_pcg *solver, int *converged, int *breakdown);
+/* relative residual norms 0..iterations (needs logging>0); returns how many were written */
+int mk_pcg_get_residual_history(const mk_pcg *solver, double *norms, int capacity);
+int mk_pcg_destroy(mk_pcg *solver);                               /* HYPRE_ParCSRPCGDestroy :775 */
+
+/* ---- plain Jacobi iteration, extension solver id 70 --------------- */
+int mk_jacobi_create(mk_jacobi **solver);
+int mk_jacobi_set_max_iter(mk_jacobi *solver, int max_iter);
+int mk_jacobi_set_tol(mk_jacobi *solver, double tol);
+int mk_jacobi_set_check_every(mk_jacobi *solver, int iterations);
+int mk_jacobi_setup(mk_jacobi *solver, const mk_matrix *A, const mk_vector *b, const mk_vector *x);
+int mk_jacobi_solve(mk_jacobi *solver, const mk_matrix *A, const mk_vector *b, mk_vector *x);
+int mk_jacobi_get_num_iterations(const mk_jacobi *solver, long long *iterations);
+int mk_jacobi_get_final_relative_residual_norm(const mk_jacobi *solver, double *norm);
+int mk_jacobi_get_converged(const mk_jacobi *solver, int *converged);
+int mk_jacobi_destroy(mk_jacobi *solver);
+
+/* ---- row-block partition: solvers.c:214-231,270-281 with defects Q1-Q4 repaired ----------- */
+/* host-only; rowptr64 has nrows+1 entries; row_start gets nparts+1 entries */
+int mk_partition_rows(int64_t nrows, const int64_t *rowptr64, int nparts, int64_t *row_start);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MK_KRYLOV_H */

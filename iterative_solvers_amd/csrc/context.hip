@@ -1,0 +1,202 @@
+// context.hip -- library life cycle, error text, vectors, timers, host-side partitioner.
+#include "mk_internal.h"
+
+namespace mk {
+
+static thread_local char g_err[1024] = "no error";
+
+void set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int fail(int code, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+Context &ctx() {
+  static Context c;
+  return c;
+}
+
+__global__ void fill_kernel(double *p, int64_t n, double v) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) p[i] = v;
+}
+
+}  // namespace mk
+
+using namespace mk;
+
+extern "C" {
+
+const char *mk_last_error_string(void) { return g_err; }
+
+int mk_init(int device_id) {
+  Context &c = ctx();
+  if (c.ready) {
+    if (c.device == device_id) return MK_OK;
+    return fail(MK_ERR_INVALID, "mk_init: already initialised on device %d", c.device);
+  }
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev == 0)
+    return fail(MK_ERR_NO_DEVICE, "mk_init: no HIP device visible (%s)", hipGetErrorString(e));
+  if (device_id < 0 || device_id >= ndev)
+    return fail(MK_ERR_INVALID, "mk_init: device %d out of range (0..%d)", device_id, ndev - 1);
+  MK_HIP(hipSetDevice(device_id));
+  hipDeviceProp_t prop;
+  MK_HIP(hipGetDeviceProperties(&prop, device_id));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(MK_ERR_NO_DEVICE, "mk_init: device %d is %s; this library is built for gfx950 only",
+                device_id, prop.gcnArchName);
+  c.device = device_id;
+  c.num_cus = prop.multiProcessorCount;
+  MK_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+  MK_HIP(hipEventCreate(&c.ev0));
+  MK_HIP(hipEventCreate(&c.ev1));
+  c.pinned_bytes = 1 << 16;
+  MK_HIP(hipHostMalloc(&c.pinned, c.pinned_bytes, hipHostMallocDefault));
+  MK_TRY(dev_alloc(&c.slab, (size_t)kMaxParts * kSlabStride));
+  MK_TRY(dev_alloc(&c.scalars, 8));
+  c.ready = true;
+  return MK_OK;
+}
+
+int mk_finalize(void) {
+  Context &c = ctx();
+  if (!c.ready) return MK_OK;
+  (void)hipStreamSynchronize(c.stream);
+  (void)hipEventDestroy(c.ev0);
+  (void)hipEventDestroy(c.ev1);
+  (void)hipHostFree(c.pinned);
+  dev_free(c.slab);
+  dev_free(c.scalars);
+  (void)hipStreamDestroy(c.stream);
+  c = Context();
+  return MK_OK;
+}
+
+void *mk_get_stream(void) { return ctx().ready ? (void *)ctx().stream : nullptr; }
+
+int mk_synchronize(void) {
+  MK_REQUIRE_INIT();
+  MK_HIP(hipStreamSynchronize(ctx().stream));
+  return MK_OK;
+}
+
+int mk_timer_start(void) {
+  MK_REQUIRE_INIT();
+  MK_HIP(hipEventRecord(ctx().ev0, ctx().stream));
+  return MK_OK;
+}
+
+int mk_timer_stop(float *elapsed_ms) {
+  MK_REQUIRE_INIT();
+  if (!elapsed_ms) return fail(MK_ERR_INVALID, "mk_timer_stop: null output");
+  MK_HIP(hipEventRecord(ctx().ev1, ctx().stream));
+  MK_HIP(hipEventSynchronize(ctx().ev1));
+  MK_HIP(hipEventElapsedTime(elapsed_ms, ctx().ev0, ctx().ev1));
+  return MK_OK;
+}
+
+// ------------------------------------------------------------------------- vectors
+
+int mk_vector_create(int64_t n, mk_vector **v) {
+  MK_REQUIRE_INIT();
+  if (!v || n < 0) return fail(MK_ERR_INVALID, "mk_vector_create: bad arguments");
+  mk_vector *p = new mk_vector();
+  p->n = n;
+  int rc = dev_alloc(&p->d, (size_t)n);
+  if (rc != MK_OK) {
+    delete p;
+    return rc;
+  }
+  *v = p;
+  return MK_OK;
+}
+
+int mk_vector_set(mk_vector *v, const double *host_values) {
+  MK_REQUIRE_INIT();
+  if (!v || (!host_values && v->n)) return fail(MK_ERR_INVALID, "mk_vector_set: null argument");
+  if (v->n) {
+    MK_HIP(hipMemcpyAsync(v->d, host_values, sizeof(double) * v->n, hipMemcpyHostToDevice, ctx().stream));
+    MK_HIP(hipStreamSynchronize(ctx().stream));
+  }
+  return MK_OK;
+}
+
+int mk_vector_fill(mk_vector *v, double value) {
+  MK_REQUIRE_INIT();
+  if (!v) return fail(MK_ERR_INVALID, "mk_vector_fill: null vector");
+  if (v->n) {
+    int blocks = (int)((v->n + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(fill_kernel, dim3(blocks), dim3(256), 0, ctx().stream, v->d, v->n, value);
+    MK_HIP(hipGetLastError());
+  }
+  return MK_OK;
+}
+
+int mk_vector_get(const mk_vector *v, double *host_values) {
+  MK_REQUIRE_INIT();
+  if (!v || (!host_values && v->n)) return fail(MK_ERR_INVALID, "mk_vector_get: null argument");
+  if (v->n) {
+    MK_HIP(hipMemcpyAsync(host_values, v->d, sizeof(double) * v->n, hipMemcpyDeviceToHost, ctx().stream));
+    MK_HIP(hipStreamSynchronize(ctx().stream));
+  }
+  return MK_OK;
+}
+
+int mk_vector_destroy(mk_vector *v) {
+  if (!v) return MK_OK;
+  if (ctx().ready) (void)hipStreamSynchronize(ctx().stream);
+  dev_free(v->d);
+  delete v;
+  return MK_OK;
+}
+
+int64_t mk_vector_size(const mk_vector *v) { return v ? v->n : -1; }
+
+// --------------------------------------------------------------------- partitioner
+// solvers.c:214-231 walks the row-sorted COO: start at nnz/np, run to the end of the row
+// that index falls in, record, step by nnz/np again, force the last part to the end.  Here
+// the same walk runs on the row-pointer array with exclusive ends and 64-bit offsets, and
+// rows without entries between two parts stay with the earlier part.
+int mk_partition_rows(int64_t nrows, const int64_t *rowptr, int nparts, int64_t *row_start) {
+  if (!rowptr || !row_start || nparts < 1 || nrows < 0)
+    return fail(MK_ERR_INVALID, "mk_partition_rows: bad arguments");
+  const int64_t nnz = rowptr[nrows];
+  const int64_t step = nnz / nparts;
+  int64_t cursor = step;
+  row_start[0] = 0;
+  for (int part = 0; part < nparts; part++) {
+    int64_t end_row;
+    if (part == nparts - 1 || cursor >= nnz) {
+      end_row = nrows;
+    } else {
+      int64_t lo = 0, hi = nrows;  // largest row with rowptr[row] <= cursor
+      while (hi - lo > 1) {
+        const int64_t mid = lo + (hi - lo) / 2;
+        if (rowptr[mid] <= cursor) lo = mid; else hi = mid;
+      }
+      end_row = lo + 1;
+      cursor = rowptr[end_row];
+      while (end_row < nrows && rowptr[end_row + 1] == rowptr[end_row]) end_row++;
+    }
+    if (end_row < row_start[part]) end_row = row_start[part];
+    row_start[part + 1] = end_row;
+    cursor += step;
+  }
+  row_start[nparts] = nrows;
+  return MK_OK;
+}
+
+}  // extern "C"

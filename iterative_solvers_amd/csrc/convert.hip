@@ -1,0 +1,535 @@
+// convert.hip -- COO -> row-sorted COO -> CSR on the device, bit-exact against the
+// reference's serial counting sort (sparse_matrix.c:471-513 sort_coo_row and :649-742
+// convert_coo_to_csr).
+//
+// What "bit-exact" means here: the reference places entry i of row r at
+// rowptr[r] + (number of earlier entries of row r), i.e. a STABLE sort by row; columns
+// inside a row keep input order (the per-row column sort is commented out, :714-735).
+// A per-row atomic cursor would not be stable, so the device path is a stable LSD radix
+// sort on the row key carrying (col, val) along, 8 key bits per pass (1..4 passes for
+// the bits nrows needs), followed by a boundary scan of the sorted keys that writes
+// row_pointers.  Integer/byte work, HBM-bound: no MFMA.
+//
+// Per pass: digit histogram per tile (reads 4 B/entry) -> exclusive scan of the
+// [digit][tile] table -> stable scatter (reads 16 B, writes 16 B per entry).
+// Inputs that are already row-sorted (the usual .mtx case) skip the sort entirely.
+#include "mk_internal.h"
+
+namespace mk {
+
+// ------------------------------------------------------------------ exclusive scan
+constexpr int kScanThreads = 256;
+constexpr int kScanItems = 16;
+constexpr int kScanChunk = kScanThreads * kScanItems;  // 4096
+
+__global__ __launch_bounds__(kScanThreads) void scan_reduce_kernel(const uint32_t *__restrict__ in, size_t n,
+                                                                   uint32_t *__restrict__ sums) {
+  __shared__ uint32_t sh[kScanThreads / 64];
+  const size_t base = (size_t)blockIdx.x * kScanChunk;
+  uint32_t s = 0;
+  for (int k = 0; k < kScanItems; k++) {
+    const size_t i = base + (size_t)k * kScanThreads + threadIdx.x;
+    if (i < n) s += in[i];
+  }
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t t = 0;
+    for (int w = 0; w < kScanThreads / 64; w++) t += sh[w];
+    sums[blockIdx.x] = t;
+  }
+}
+
+// one block scans up to kScanChunk*? entries serially in chunks (used for the top level)
+__global__ __launch_bounds__(kScanThreads) void scan_single_block_kernel(const uint32_t *in, uint32_t *out, size_t n,
+                                                                         uint32_t *total) {
+  __shared__ uint32_t sh[kScanThreads];
+  uint32_t carry = 0;
+  for (size_t base = 0; base < n; base += kScanThreads) {
+    const size_t i = base + threadIdx.x;
+    const uint32_t v = (i < n) ? in[i] : 0u;
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = 1; off < kScanThreads; off <<= 1) {
+      uint32_t t = (threadIdx.x >= (unsigned)off) ? sh[threadIdx.x - off] : 0u;
+      __syncthreads();
+      sh[threadIdx.x] += t;
+      __syncthreads();
+    }
+    if (i < n) out[i] = carry + sh[threadIdx.x] - v;
+    const uint32_t tot = sh[kScanThreads - 1];
+    __syncthreads();
+    carry += tot;
+  }
+  if (threadIdx.x == 0 && total) *total = carry;
+}
+
+__global__ __launch_bounds__(kScanThreads) void scan_apply_kernel(const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
+                                                                  size_t n, const uint32_t *__restrict__ chunk_offsets) {
+  // thread t owns kScanItems consecutive entries of its block's chunk
+  __shared__ uint32_t sh[kScanThreads];
+  const size_t base = (size_t)blockIdx.x * kScanChunk + (size_t)threadIdx.x * kScanItems;
+  uint32_t v[kScanItems];
+  uint32_t s = 0;
+#pragma unroll
+  for (int k = 0; k < kScanItems; k++) {
+    v[k] = (base + k < n) ? in[base + k] : 0u;
+    s += v[k];
+  }
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 1; off < kScanThreads; off <<= 1) {
+    uint32_t t = (threadIdx.x >= (unsigned)off) ? sh[threadIdx.x - off] : 0u;
+    __syncthreads();
+    sh[threadIdx.x] += t;
+    __syncthreads();
+  }
+  uint32_t run = chunk_offsets[blockIdx.x] + sh[threadIdx.x] - s;
+#pragma unroll
+  for (int k = 0; k < kScanItems; k++) {
+    if (base + k < n) out[base + k] = run;
+    run += v[k];
+  }
+}
+
+int exclusive_scan_u32(const uint32_t *in, uint32_t *out, size_t n, uint32_t *total_out_dev) {
+  Context &c = ctx();
+  if (n == 0) {
+    if (total_out_dev) MK_HIP(hipMemsetAsync(total_out_dev, 0, sizeof(uint32_t), c.stream));
+    return MK_OK;
+  }
+  if (n <= (size_t)kScanChunk) {
+    hipLaunchKernelGGL(scan_single_block_kernel, dim3(1), dim3(kScanThreads), 0, c.stream, in, out, n, total_out_dev);
+    MK_HIP(hipGetLastError());
+    return MK_OK;
+  }
+  const size_t nchunks = (n + kScanChunk - 1) / kScanChunk;
+  uint32_t *sums = nullptr;
+  MK_TRY(dev_alloc(&sums, nchunks));
+  hipLaunchKernelGGL(scan_reduce_kernel, dim3((unsigned)nchunks), dim3(kScanThreads), 0, c.stream, in, n, sums);
+  int rc = exclusive_scan_u32(sums, sums, nchunks, total_out_dev);  // in place is fine for both scan forms
+  if (rc == MK_OK) {
+    hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)nchunks), dim3(kScanThreads), 0, c.stream, in, out, n, sums);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) rc = fail(MK_ERR_HIP, "scan_apply: %s", hipGetErrorString(e));
+  }
+  // sums is still in use by queued kernels: free after they drain
+  (void)hipStreamSynchronize(c.stream);
+  dev_free(sums);
+  return rc;
+}
+
+// ------------------------------------------------------------------ input checks
+struct CooCheck {
+  int unsorted;      // some rows[i] < rows[i-1]
+  int bad_row;       // row outside [0,nrows)
+  int bad_col;       // col outside [0,ncols)
+};
+
+__global__ void coo_check_kernel(int64_t nnz, int64_t nrows, int64_t ncols, const int *__restrict__ rows,
+                                 const int *__restrict__ cols, CooCheck *out) {
+  int unsorted = 0, bad_row = 0, bad_col = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += (int64_t)gridDim.x * blockDim.x) {
+    const int r = rows[i], cc = cols[i];
+    if (r < 0 || r >= nrows) bad_row = 1;
+    if (cc < 0 || cc >= ncols) bad_col = 1;
+    if (i > 0 && rows[i - 1] > r) unsorted = 1;
+  }
+  if (__any(unsorted) && (threadIdx.x & 63) == 0) out->unsorted = 1;
+  if (__any(bad_row) && (threadIdx.x & 63) == 0) out->bad_row = 1;
+  if (__any(bad_col) && (threadIdx.x & 63) == 0) out->bad_col = 1;
+}
+
+// ------------------------------------------------------------------- radix passes
+constexpr int kRadixBits = 8;
+constexpr int kRadix = 1 << kRadixBits;
+constexpr int kSortThreads = 512;
+constexpr int kSortWaves = kSortThreads / 64;
+constexpr int kSortItems = 16;
+constexpr int kSortTile = kSortThreads * kSortItems;  // 8192 entries per block
+constexpr int kWaveSpan = 64 * kSortItems;            // consecutive entries owned by one wave
+
+// table[digit * ntiles + tile] = number of keys of that digit in the tile
+__global__ __launch_bounds__(kSortThreads) void radix_hist_kernel(const int *__restrict__ keys, int64_t n, int shift,
+                                                                  unsigned mask, uint32_t *__restrict__ table, int ntiles) {
+  __shared__ unsigned int h[kRadix];
+  for (int i = threadIdx.x; i < kRadix; i += kSortThreads) h[i] = 0;
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * kSortTile;
+#pragma unroll 4
+  for (int k = 0; k < kSortItems; k++) {
+    const int64_t i = base + (int64_t)k * kSortThreads + threadIdx.x;
+    if (i < n) atomicAdd(&h[((unsigned)keys[i] >> shift) & mask], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < kRadix; i += kSortThreads) table[(size_t)i * ntiles + blockIdx.x] = h[i];
+}
+
+// Stable scatter.  Order inside a tile is (wave, item, lane): wave w owns entries
+// [w*kWaveSpan, (w+1)*kWaveSpan) of the tile and walks them 64 at a time, so the rank of
+// an entry among equal digits = (entries of that digit in earlier waves) + (in earlier
+// items of this wave) + (in lower lanes of this item).
+__global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
+    const int *__restrict__ keys_in, const int *__restrict__ cols_in, const double *__restrict__ vals_in,
+    int *__restrict__ keys_out, int *__restrict__ cols_out, double *__restrict__ vals_out, int64_t n, int shift,
+    unsigned mask, const uint32_t *__restrict__ table_scanned, int ntiles) {
+  __shared__ unsigned int cnt[kSortWaves][kRadix];   // running count per wave and digit
+  __shared__ unsigned int gbase[kRadix];             // global offset of (digit, this tile)
+  for (int i = threadIdx.x; i < kSortWaves * kRadix; i += kSortThreads) (&cnt[0][0])[i] = 0;
+  for (int i = threadIdx.x; i < kRadix; i += kSortThreads) gbase[i] = table_scanned[(size_t)i * ntiles + blockIdx.x];
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t wbase = (int64_t)blockIdx.x * kSortTile + (int64_t)w * kWaveSpan;
+  const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  unsigned int rank[kSortItems];
+  unsigned int digit[kSortItems];
+  volatile unsigned int *mycnt = cnt[w];
+#pragma unroll
+  for (int k = 0; k < kSortItems; k++) {
+    const int64_t i = wbase + (int64_t)k * 64 + lane;
+    const bool valid = i < n;
+    const unsigned d = valid ? (((unsigned)keys_in[i] >> shift) & mask) : 0u;
+    unsigned long long peers = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < kRadixBits; b++) {
+      const unsigned long long bal = __ballot((d >> b) & 1u);
+      peers &= ((d >> b) & 1u) ? bal : ~bal;
+    }
+    const unsigned before = (unsigned)__popcll(peers & lt);
+    const unsigned prev = valid ? mycnt[d] : 0u;
+    digit[k] = d;
+    rank[k] = prev + before;
+    __builtin_amdgcn_wave_barrier();
+    if (valid && before == 0) mycnt[d] = prev + (unsigned)__popcll(peers);
+    __builtin_amdgcn_wave_barrier();
+  }
+  __syncthreads();
+  // per digit: turn the per-wave totals into exclusive offsets over waves
+  if (threadIdx.x < kRadix) {
+    unsigned run = 0;
+#pragma unroll
+    for (int ww = 0; ww < kSortWaves; ww++) {
+      const unsigned t = cnt[ww][threadIdx.x];
+      cnt[ww][threadIdx.x] = run;
+      run += t;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < kSortItems; k++) {
+    const int64_t i = wbase + (int64_t)k * 64 + lane;
+    if (i < n) {
+      const unsigned d = digit[k];
+      const size_t pos = (size_t)gbase[d] + cnt[w][d] + rank[k];
+      keys_out[pos] = keys_in[i];
+      cols_out[pos] = cols_in[i];
+      vals_out[pos] = vals_in[i];
+    }
+  }
+}
+
+// the histogram kernel above counts entries in (item, thread) order, the scatter kernel
+// walks (wave, item, lane); both cover exactly the tile [blockIdx*kSortTile, +kSortTile).
+
+// row_pointers from the sorted keys: entry i opens every row in (rows[i-1], rows[i]]
+__global__ void rowptr_from_sorted_kernel(int64_t nnz, int64_t nrows, const int *__restrict__ rows, int *__restrict__ rowptr) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += (int64_t)gridDim.x * blockDim.x) {
+    const int r = rows[i];
+    const int prev = (i == 0) ? -1 : rows[i - 1];
+    for (int q = prev + 1; q <= r; q++) rowptr[q] = (int)i;
+    if (i == nnz - 1)
+      for (int64_t q = (int64_t)r + 1; q <= nrows; q++) rowptr[q] = (int)nnz;
+  }
+}
+
+__global__ void fill_int_kernel(int *p, int64_t n, int v) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+static int key_bits(int64_t nrows) {
+  int bits = 1;
+  while (bits < 31 && ((int64_t)1 << bits) < nrows) bits++;
+  return bits;
+}
+
+int device_coo_to_csr(mk_coo *coo, mk_matrix *A, int **sorted_rows_out) {
+  Context &c = ctx();
+  const int64_t nnz = coo->nnz, nrows = coo->nrows;
+  if (nnz > (int64_t)0x7fffffff) return fail(MK_ERR_UNSUPPORTED, "local nnz %lld exceeds int32 row pointers", (long long)nnz);
+  A->nrows = nrows; A->ncols = coo->ncols; A->nnz = nnz;
+  MK_TRY(dev_alloc(&A->rowptr, (size_t)nrows + 1));
+
+  // 1. validate + detect the already-sorted case
+  CooCheck h{0, 0, 0}, *d_chk = nullptr;
+  MK_TRY(dev_alloc(&d_chk, 1));
+  MK_HIP(hipMemsetAsync(d_chk, 0, sizeof(CooCheck), c.stream));
+  if (nnz > 0) {
+    int blocks = (int)std::min<int64_t>((nnz + 255) / 256, 4096);
+    hipLaunchKernelGGL(coo_check_kernel, dim3(blocks), dim3(256), 0, c.stream, nnz, nrows, coo->ncols, coo->rows, coo->cols, d_chk);
+  }
+  MK_HIP(hipMemcpyAsync(&h, d_chk, sizeof(h), hipMemcpyDeviceToHost, c.stream));
+  MK_HIP(hipStreamSynchronize(c.stream));
+  dev_free(d_chk);
+  if (h.bad_row) return fail(MK_ERR_INVALID, "COO row index outside [0,%lld)", (long long)nrows);
+  if (h.bad_col) return fail(MK_ERR_INVALID, "COO column index outside [0,%lld)", (long long)coo->ncols);
+
+  int *keys = coo->rows, *cols = coo->cols;
+  double *vals = coo->vals;
+  if (h.unsorted) {
+    // 2. stable LSD radix sort on the row key
+    int *keys2 = nullptr, *cols2 = nullptr;
+    double *vals2 = nullptr;
+    uint32_t *table = nullptr;
+    const int ntiles = (int)((nnz + kSortTile - 1) / kSortTile);
+    MK_TRY(dev_alloc(&keys2, (size_t)nnz));
+    MK_TRY(dev_alloc(&cols2, (size_t)nnz));
+    MK_TRY(dev_alloc(&vals2, (size_t)nnz));
+    MK_TRY(dev_alloc(&table, (size_t)kRadix * ntiles));
+    const int bits = key_bits(nrows);
+    const int passes = (bits + kRadixBits - 1) / kRadixBits;
+    int shift = 0;
+    for (int p = 0; p < passes; p++) {
+      // spread the key bits evenly over the passes
+      const int pb = (bits - shift + (passes - p) - 1) / (passes - p);
+      const unsigned mask = (1u << pb) - 1u;
+      hipLaunchKernelGGL(radix_hist_kernel, dim3(ntiles), dim3(kSortThreads), 0, c.stream, keys, nnz, shift, mask, table, ntiles);
+      MK_HIP(hipGetLastError());
+      MK_TRY(exclusive_scan_u32(table, table, (size_t)kRadix * ntiles, nullptr));
+      hipLaunchKernelGGL(radix_scatter_kernel, dim3(ntiles), dim3(kSortThreads), 0, c.stream, keys, cols, vals, keys2, cols2,
+                         vals2, nnz, shift, mask, table, ntiles);
+      MK_HIP(hipGetLastError());
+      std::swap(keys, keys2);
+      std::swap(cols, cols2);
+      std::swap(vals, vals2);
+      shift += pb;
+    }
+    MK_HIP(hipStreamSynchronize(c.stream));
+    dev_free(keys2);
+    dev_free(cols2);
+    dev_free(vals2);
+    dev_free(table);
+  }
+  // 3. row pointers from the sorted keys
+  if (nnz == 0) {
+    int blocks = (int)std::min<int64_t>((nrows + 1 + 255) / 256, 4096);
+    hipLaunchKernelGGL(fill_int_kernel, dim3(blocks), dim3(256), 0, c.stream, A->rowptr, nrows + 1, 0);
+  } else {
+    int blocks = (int)std::min<int64_t>((nnz + 255) / 256, 8192);
+    hipLaunchKernelGGL(rowptr_from_sorted_kernel, dim3(blocks), dim3(256), 0, c.stream, nnz, nrows, keys, A->rowptr);
+  }
+  MK_HIP(hipGetLastError());
+  A->col = cols;
+  A->val = vals;
+  if (sorted_rows_out) {
+    *sorted_rows_out = keys;
+  } else {
+    MK_HIP(hipStreamSynchronize(c.stream));
+    dev_free(keys);
+  }
+  coo->rows = nullptr; coo->cols = nullptr; coo->vals = nullptr; coo->nnz = 0;
+  return MK_OK;
+}
+
+static int upload_coo(const SparseMatrixCOO *h, mk_coo *d) {
+  Context &c = ctx();
+  d->nrows = h->nrows; d->ncols = h->ncolumns; d->nnz = h->nnz;
+  MK_TRY(dev_alloc(&d->rows, (size_t)d->nnz));
+  MK_TRY(dev_alloc(&d->cols, (size_t)d->nnz));
+  MK_TRY(dev_alloc(&d->vals, (size_t)d->nnz));
+  if (d->nnz) {
+    if (!h->rows || !h->columns || !h->values) return fail(MK_ERR_INVALID, "COO arrays are null");
+    MK_HIP(hipMemcpyAsync(d->rows, h->rows, sizeof(int) * d->nnz, hipMemcpyHostToDevice, c.stream));
+    MK_HIP(hipMemcpyAsync(d->cols, h->columns, sizeof(int) * d->nnz, hipMemcpyHostToDevice, c.stream));
+    MK_HIP(hipMemcpyAsync(d->vals, h->values, sizeof(double) * d->nnz, hipMemcpyHostToDevice, c.stream));
+    MK_HIP(hipStreamSynchronize(c.stream));
+  }
+  return MK_OK;
+}
+
+static void free_coo_buffers(mk_coo *d) {
+  dev_free(d->rows); dev_free(d->cols); dev_free(d->vals);
+  d->rows = nullptr; d->cols = nullptr; d->vals = nullptr;
+}
+
+static void free_matrix_buffers(mk_matrix *A) {
+  dev_free(A->rowptr); dev_free(A->col); dev_free(A->val); dev_free(A->dinv);
+  dev_free(A->chunk_row); dev_free(A->long_rows);
+}
+
+template <typename T>
+static T *host_alloc(size_t count) {
+  size_t bytes = count * sizeof(T);
+  if (bytes == 0) bytes = 64;
+  bytes = (bytes + 63) / 64 * 64;  // aligned_alloc wants a multiple of the alignment
+  return static_cast<T *>(aligned_alloc(64, bytes));
+}
+
+}  // namespace mk
+
+using namespace mk;
+
+extern "C" {
+
+int mk_coo_from_host(const SparseMatrixCOO *coo, mk_coo **out) {
+  MK_REQUIRE_INIT();
+  if (!coo || !out) return fail(MK_ERR_INVALID, "mk_coo_from_host: null argument");
+  mk_coo *d = new mk_coo();
+  int rc = upload_coo(coo, d);
+  if (rc != MK_OK) { free_coo_buffers(d); delete d; return rc; }
+  *out = d;
+  return MK_OK;
+}
+
+int mk_coo_download(const mk_coo *coo, SparseMatrixCOO *out) {
+  MK_REQUIRE_INIT();
+  if (!coo || !out) return fail(MK_ERR_INVALID, "mk_coo_download: null argument");
+  Context &c = ctx();
+  out->nrows = (unsigned)coo->nrows; out->ncolumns = (unsigned)coo->ncols; out->nnz = (unsigned)coo->nnz;
+  out->rows = host_alloc<int>((size_t)coo->nnz);
+  out->columns = host_alloc<int>((size_t)coo->nnz);
+  out->values = host_alloc<double>((size_t)coo->nnz);
+  if (!out->rows || !out->columns || !out->values) return fail(MK_ERR_ALLOC, "mk_coo_download: host allocation failed");
+  if (coo->nnz) {
+    MK_HIP(hipMemcpyAsync(out->rows, coo->rows, sizeof(int) * coo->nnz, hipMemcpyDeviceToHost, c.stream));
+    MK_HIP(hipMemcpyAsync(out->columns, coo->cols, sizeof(int) * coo->nnz, hipMemcpyDeviceToHost, c.stream));
+    MK_HIP(hipMemcpyAsync(out->values, coo->vals, sizeof(double) * coo->nnz, hipMemcpyDeviceToHost, c.stream));
+    MK_HIP(hipStreamSynchronize(c.stream));
+  }
+  return MK_OK;
+}
+
+int mk_coo_destroy(mk_coo *coo) {
+  if (!coo) return MK_OK;
+  if (ctx().ready) (void)hipStreamSynchronize(ctx().stream);
+  free_coo_buffers(coo);
+  delete coo;
+  return MK_OK;
+}
+
+int mk_matrix_from_device_coo(mk_coo *coo, mk_matrix **A) {
+  MK_REQUIRE_INIT();
+  if (!coo || !A) return fail(MK_ERR_INVALID, "mk_matrix_from_device_coo: null argument");
+  mk_matrix *M = new mk_matrix();
+  int rc = device_coo_to_csr(coo, M, nullptr);
+  if (rc != MK_OK) { free_matrix_buffers(M); delete M; return rc; }
+  *A = M;
+  return MK_OK;
+}
+
+int mk_matrix_from_coo(const SparseMatrixCOO *coo, mk_matrix **A) {
+  MK_REQUIRE_INIT();
+  if (!coo || !A) return fail(MK_ERR_INVALID, "mk_matrix_from_coo: null argument");
+  mk_coo d;
+  int rc = upload_coo(coo, &d);
+  if (rc != MK_OK) { free_coo_buffers(&d); return rc; }
+  mk_matrix *M = new mk_matrix();
+  rc = device_coo_to_csr(&d, M, nullptr);
+  free_coo_buffers(&d);
+  if (rc != MK_OK) { free_matrix_buffers(M); delete M; return rc; }
+  *A = M;
+  return MK_OK;
+}
+
+int mk_matrix_from_csr(const SparseMatrixCSR *csr, mk_matrix **A) {
+  MK_REQUIRE_INIT();
+  if (!csr || !A) return fail(MK_ERR_INVALID, "mk_matrix_from_csr: null argument");
+  if (!csr->row_pointers || (csr->nnz && (!csr->column_indices || !csr->values)))
+    return fail(MK_ERR_INVALID, "mk_matrix_from_csr: null array");
+  if (csr->nnz > 0x7fffffffu) return fail(MK_ERR_UNSUPPORTED, "mk_matrix_from_csr: nnz exceeds int32");
+  // host-side shape check before anything reaches a kernel
+  if (csr->row_pointers[0] != 0 || (unsigned)csr->row_pointers[csr->nrows] != csr->nnz)
+    return fail(MK_ERR_INVALID, "mk_matrix_from_csr: row_pointers[0]=%d, row_pointers[nrows]=%d, nnz=%u",
+                csr->row_pointers[0], csr->row_pointers[csr->nrows], csr->nnz);
+  for (unsigned r = 0; r < csr->nrows; r++)
+    if (csr->row_pointers[r + 1] < csr->row_pointers[r])
+      return fail(MK_ERR_INVALID, "mk_matrix_from_csr: row_pointers decrease at row %u", r);
+  for (unsigned k = 0; k < csr->nnz; k++)
+    if (csr->column_indices[k] < 0 || (unsigned)csr->column_indices[k] >= csr->ncolumns)
+      return fail(MK_ERR_INVALID, "mk_matrix_from_csr: column index %d at entry %u outside [0,%u)",
+                  csr->column_indices[k], k, csr->ncolumns);
+  Context &c = ctx();
+  mk_matrix *M = new mk_matrix();
+  M->nrows = csr->nrows; M->ncols = csr->ncolumns; M->nnz = csr->nnz;
+  int rc = dev_alloc(&M->rowptr, (size_t)M->nrows + 1);
+  if (rc == MK_OK) rc = dev_alloc(&M->col, (size_t)M->nnz);
+  if (rc == MK_OK) rc = dev_alloc(&M->val, (size_t)M->nnz);
+  if (rc != MK_OK) { free_matrix_buffers(M); delete M; return rc; }
+  hipError_t e = hipMemcpyAsync(M->rowptr, csr->row_pointers, sizeof(int) * (M->nrows + 1), hipMemcpyHostToDevice, c.stream);
+  if (e == hipSuccess && M->nnz) e = hipMemcpyAsync(M->col, csr->column_indices, sizeof(int) * M->nnz, hipMemcpyHostToDevice, c.stream);
+  if (e == hipSuccess && M->nnz) e = hipMemcpyAsync(M->val, csr->values, sizeof(double) * M->nnz, hipMemcpyHostToDevice, c.stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c.stream);
+  if (e != hipSuccess) { free_matrix_buffers(M); delete M; return fail(MK_ERR_HIP, "mk_matrix_from_csr: %s", hipGetErrorString(e)); }
+  *A = M;
+  return MK_OK;
+}
+
+int mk_matrix_destroy(mk_matrix *A) {
+  if (!A) return MK_OK;
+  if (ctx().ready) (void)hipStreamSynchronize(ctx().stream);
+  free_matrix_buffers(A);
+  delete A;
+  return MK_OK;
+}
+
+int mk_matrix_get_csr(const mk_matrix *A, SparseMatrixCSR *csr) {
+  MK_REQUIRE_INIT();
+  if (!A || !csr) return fail(MK_ERR_INVALID, "mk_matrix_get_csr: null argument");
+  Context &c = ctx();
+  csr->nrows = (unsigned)A->nrows; csr->ncolumns = (unsigned)A->ncols; csr->nnz = (unsigned)A->nnz;
+  csr->row_pointers = host_alloc<int>((size_t)A->nrows + 1);
+  csr->column_indices = host_alloc<int>((size_t)A->nnz);
+  csr->values = host_alloc<double>((size_t)A->nnz);
+  if (!csr->row_pointers || !csr->column_indices || !csr->values) return fail(MK_ERR_ALLOC, "mk_matrix_get_csr: host allocation failed");
+  MK_HIP(hipMemcpyAsync(csr->row_pointers, A->rowptr, sizeof(int) * (A->nrows + 1), hipMemcpyDeviceToHost, c.stream));
+  if (A->nnz) {
+    MK_HIP(hipMemcpyAsync(csr->column_indices, A->col, sizeof(int) * A->nnz, hipMemcpyDeviceToHost, c.stream));
+    MK_HIP(hipMemcpyAsync(csr->values, A->val, sizeof(double) * A->nnz, hipMemcpyDeviceToHost, c.stream));
+  }
+  MK_HIP(hipStreamSynchronize(c.stream));
+  return MK_OK;
+}
+
+int mk_coo_to_csr(const SparseMatrixCOO *coo, SparseMatrixCSR *csr) {
+  MK_REQUIRE_INIT();
+  if (!coo || !csr) return fail(MK_ERR_INVALID, "mk_coo_to_csr: null argument");
+  mk_matrix *M = nullptr;
+  MK_TRY(mk_matrix_from_coo(coo, &M));
+  int rc = mk_matrix_get_csr(M, csr);
+  mk_matrix_destroy(M);
+  return rc;
+}
+
+int mk_sort_coo_row(const SparseMatrixCOO *coo, SparseMatrixCOO *sorted) {
+  MK_REQUIRE_INIT();
+  if (!coo || !sorted) return fail(MK_ERR_INVALID, "mk_sort_coo_row: null argument");
+  Context &c = ctx();
+  mk_coo d;
+  int rc = upload_coo(coo, &d);
+  if (rc != MK_OK) { free_coo_buffers(&d); return rc; }
+  mk_matrix M;
+  int *keys = nullptr;
+  rc = device_coo_to_csr(&d, &M, &keys);
+  free_coo_buffers(&d);
+  if (rc != MK_OK) { free_matrix_buffers(&M); return rc; }
+  sorted->nrows = coo->nrows; sorted->ncolumns = coo->ncolumns; sorted->nnz = coo->nnz;
+  sorted->rows = host_alloc<int>(coo->nnz);
+  sorted->columns = host_alloc<int>(coo->nnz);
+  sorted->values = host_alloc<double>(coo->nnz);
+  hipError_t e = hipSuccess;
+  if (!sorted->rows || !sorted->columns || !sorted->values) rc = fail(MK_ERR_ALLOC, "mk_sort_coo_row: host allocation failed");
+  if (rc == MK_OK && coo->nnz) {
+    e = hipMemcpyAsync(sorted->rows, keys, sizeof(int) * coo->nnz, hipMemcpyDeviceToHost, c.stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(sorted->columns, M.col, sizeof(int) * coo->nnz, hipMemcpyDeviceToHost, c.stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(sorted->values, M.val, sizeof(double) * coo->nnz, hipMemcpyDeviceToHost, c.stream);
+  }
+  hipError_t e2 = hipStreamSynchronize(c.stream);
+  if (e == hipSuccess) e = e2;
+  if (rc == MK_OK && e != hipSuccess) rc = fail(MK_ERR_HIP, "mk_sort_coo_row: %s", hipGetErrorString(e));
+  dev_free(keys);
+  free_matrix_buffers(&M);
+  return rc;
+}
+
+}  // extern "C"

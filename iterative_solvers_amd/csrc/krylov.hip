@@ -1,0 +1,617 @@
+// krylov.hip -- fused CG (HYPRE-PCG semantics) and plain Jacobi on one GPU.
+//
+// Stands in for HYPRE_ParCSRPCGSetup/Solve as the reference drives them for solver id 50
+// (solvers.c:729-775: MaxIter, Tol, TwoNorm=1, RelChange=1, Logging=1, identity
+// preconditioner).  hypre_PCGSolve itself is not in /root/reference; the loop follows its
+// published algorithm (see oracle/oracle.c orc_pcg for the step list).  Extension: diagonal
+// scaling as preconditioner (HYPRE_ParCSRDiagScale semantics), solver id 51.
+//
+// One iteration = three kernels and two grid-level reductions, nothing returns to the host:
+//   K1  s = A p          + per-block partials of <s,p>, <p,p>                (spmv.hip)
+//   K2  alpha = gamma/<s,p>;  x += alpha p;  r -= alpha s;  z = C r (not stored)
+//                         + partials of <r,z>, <r,r>, <x,x>
+//   K3  beta = gamma'/gamma;  convergence test;  p = C r + beta p
+// Each reduction is finished by the NEXT kernel's prologue (every block sums the slab of
+// partials in a fixed order), so there is no in-launch inter-workgroup hand-off and the
+// result is bitwise reproducible.  Scalars live in a device-side state record; the host
+// polls its stop flag every `check_every` iterations, and kernels launched after the flag
+// is raised return at once, so the reported iteration count is exact.
+// Algorithmic bytes per iteration: 12*nnz + 92*n (identity) / 12*nnz + 108*n (Jacobi).
+#include <cfloat>
+#include <cmath>
+
+#include "mk_internal.h"
+
+namespace mk {
+
+constexpr int kVecThreads = 256;
+
+struct PcgState {
+  double gamma, gamma_old, alpha, pp, i_prod, bi_prod, eps, sdotp;
+  long long iter;
+  int done;        // 0 running, 1 converged, 2 breakdown
+  int converged;
+  int breakdown;   // 1 zero <s,p>, 2 subnormal alpha, 3 subnormal gamma
+  int pad;
+};
+
+// p = z = C r; partials of <b,b> (or <Cb,b>), <r,z>, <r,r>
+__global__ __launch_bounds__(kVecThreads) void pcg_init_vectors_kernel(int64_t n, const double *__restrict__ b,
+                                                                       const double *__restrict__ r,
+                                                                       const double *__restrict__ dinv,
+                                                                       double *__restrict__ p, int two_norm,
+                                                                       double *__restrict__ slab) {
+  double v[3] = {0.0, 0.0, 0.0};
+  for (int64_t i = (int64_t)blockIdx.x * kVecThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kVecThreads) {
+    const double bi = b[i], ri = r[i];
+    const double di = dinv ? dinv[i] : 1.0;
+    const double zi = dinv ? ri * di : ri;
+    p[i] = zi;
+    v[0] += two_norm ? bi * bi : (bi * di) * bi;
+    v[1] += ri * zi;
+    v[2] += ri * ri;
+  }
+  __shared__ double smem[3 * (kVecThreads / 64)];
+  block_sum<3, kVecThreads>(v, smem);
+  if (threadIdx.x == 0)
+    for (int k = 0; k < 3; k++) slab[k * kSlabStride + blockIdx.x] = v[k];
+}
+
+__global__ __launch_bounds__(kVecThreads) void pcg_init_scalars_kernel(const double *slab, int nblocks, double tol,
+                                                                       int two_norm, PcgState *st, double *norms) {
+  __shared__ double smem[3 * (kVecThreads / 64)];
+  double v[3];
+  reduce_slab<3, kVecThreads>(slab, nblocks, v, smem);
+  if (threadIdx.x == 0) {
+    PcgState s;
+    memset(&s, 0, sizeof(s));
+    s.bi_prod = v[0];
+    s.gamma = v[1];
+    s.i_prod = two_norm ? v[2] : v[1];
+    s.eps = tol * tol;
+    s.done = (v[0] > 0.0) ? 0 : 1;  // zero right-hand side: x = b, nothing to iterate
+    *st = s;
+    if (norms) norms[0] = (v[0] > 0.0) ? sqrt(s.i_prod / v[0]) : 0.0;
+  }
+}
+
+// K2
+template <bool PRECOND>
+__global__ __launch_bounds__(kVecThreads) void pcg_update_xr_kernel(int64_t n, const double *__restrict__ p,
+                                                                    const double *__restrict__ s, const double *__restrict__ dinv,
+                                                                    double *__restrict__ x, double *__restrict__ r,
+                                                                    const double *__restrict__ slab_in, int nblocks_in,
+                                                                    double *__restrict__ slab_out, PcgState *st) {
+  if (st->done != 0) return;
+  __shared__ double smem[3 * (kVecThreads / 64)];
+  double d[2];
+  reduce_slab<2, kVecThreads>(slab_in, nblocks_in, d, smem);
+  const double sdotp = d[0], pp = d[1];
+  const double gamma = st->gamma;
+  const bool leader = (blockIdx.x == 0 && threadIdx.x == 0);
+  if (sdotp == 0.0) {
+    if (leader) { st->iter += 1; st->breakdown = 1; st->done = 2; }
+    return;
+  }
+  const double alpha = gamma / sdotp;
+  if (!(alpha > DBL_MIN)) {
+    if (leader) { st->iter += 1; st->breakdown = 2; st->done = 2; }
+    return;
+  }
+  double v[3] = {0.0, 0.0, 0.0};
+  const int64_t n2 = n >> 1;
+  const double2 *p2 = reinterpret_cast<const double2 *>(p);
+  const double2 *s2 = reinterpret_cast<const double2 *>(s);
+  const double2 *d2 = reinterpret_cast<const double2 *>(dinv);
+  double2 *x2 = reinterpret_cast<double2 *>(x);
+  double2 *r2 = reinterpret_cast<double2 *>(r);
+  for (int64_t i = (int64_t)blockIdx.x * kVecThreads + threadIdx.x; i < n2; i += (int64_t)gridDim.x * kVecThreads) {
+    const double2 pv = p2[i], sv = s2[i];
+    double2 xv = x2[i], rv = r2[i];
+    xv.x += alpha * pv.x; xv.y += alpha * pv.y;
+    rv.x -= alpha * sv.x; rv.y -= alpha * sv.y;
+    x2[i] = xv;
+    r2[i] = rv;
+    double zx = rv.x, zy = rv.y;
+    if (PRECOND) { const double2 dv = d2[i]; zx *= dv.x; zy *= dv.y; }
+    v[0] += rv.x * zx + rv.y * zy;
+    v[1] += rv.x * rv.x + rv.y * rv.y;
+    v[2] += xv.x * xv.x + xv.y * xv.y;
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const int64_t i = n - 1;
+    const double xi = x[i] + alpha * p[i], ri = r[i] - alpha * s[i];
+    x[i] = xi; r[i] = ri;
+    const double zi = PRECOND ? ri * dinv[i] : ri;
+    v[0] += ri * zi; v[1] += ri * ri; v[2] += xi * xi;
+  }
+  block_sum<3, kVecThreads>(v, smem);
+  if (threadIdx.x == 0)
+    for (int k = 0; k < 3; k++) slab_out[k * kSlabStride + blockIdx.x] = v[k];
+  if (leader) { st->alpha = alpha; st->gamma_old = gamma; st->pp = pp; st->sdotp = sdotp; st->iter += 1; }
+}
+
+// K3
+template <bool PRECOND>
+__global__ __launch_bounds__(kVecThreads) void pcg_update_p_kernel(int64_t n, const double *__restrict__ r,
+                                                                   const double *__restrict__ dinv, double *__restrict__ p,
+                                                                   const double *__restrict__ slab_in, int nblocks_in,
+                                                                   int two_norm, int rel_change, PcgState *st,
+                                                                   double *__restrict__ norms) {
+  if (st->done != 0) return;
+  __shared__ double smem[3 * (kVecThreads / 64)];
+  double d[3];
+  reduce_slab<3, kVecThreads>(slab_in, nblocks_in, d, smem);
+  const double gamma_new = d[0];
+  const double i_prod = two_norm ? d[1] : d[0];
+  const double xx = d[2];
+  const double bi_prod = st->bi_prod, eps = st->eps, alpha = st->alpha, pp = st->pp, gamma_old = st->gamma_old;
+  const bool leader = (blockIdx.x == 0 && threadIdx.x == 0);
+  bool conv = (i_prod / bi_prod < eps);
+  if (conv && rel_change && i_prod > 0.0) {
+    const double ratio = alpha * alpha * pp / xx;
+    if (ratio >= eps) conv = false;
+  }
+  const bool tiny_gamma = (gamma_new < DBL_MIN) && (-gamma_new < DBL_MIN);
+  if (leader) {
+    st->gamma = gamma_new;
+    st->i_prod = i_prod;
+    if (norms) norms[st->iter] = sqrt(i_prod / bi_prod);
+    if (conv) { st->converged = 1; st->done = 1; }
+    else if (tiny_gamma) { st->breakdown = 3; st->done = 2; }
+  }
+  if (conv || tiny_gamma) return;
+  const double beta = gamma_new / gamma_old;
+  const int64_t n2 = n >> 1;
+  const double2 *r2 = reinterpret_cast<const double2 *>(r);
+  const double2 *d2 = reinterpret_cast<const double2 *>(dinv);
+  double2 *p2 = reinterpret_cast<double2 *>(p);
+  for (int64_t i = (int64_t)blockIdx.x * kVecThreads + threadIdx.x; i < n2; i += (int64_t)gridDim.x * kVecThreads) {
+    double2 zv = r2[i];
+    if (PRECOND) { const double2 dv = d2[i]; zv.x *= dv.x; zv.y *= dv.y; }
+    double2 pv = p2[i];
+    pv.x = beta * pv.x + zv.x;
+    pv.y = beta * pv.y + zv.y;
+    p2[i] = pv;
+  }
+  if ((n & 1) && leader) {
+    const int64_t i = n - 1;
+    const double zi = PRECOND ? r[i] * dinv[i] : r[i];
+    p[i] = beta * p[i] + zi;
+  }
+}
+
+__global__ void copy_kernel(double *__restrict__ dst, const double *__restrict__ src, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+static int vec_blocks(int64_t n) {
+  int64_t want = (n / 2 + kVecThreads - 1) / kVecThreads;
+  int64_t cap = (int64_t)ctx().num_cus * 8;
+  if (cap > kSlabStride) cap = kSlabStride;
+  return (int)std::max<int64_t>(1, std::min(want, cap));
+}
+
+}  // namespace mk
+
+struct mk_pcg {
+  int max_iter = 1000;      // solvers.c:83
+  double tol = 1e-6;        // solvers.c:84
+  int two_norm = 0;         // HYPRE defaults; the driver sets both to 1 (solvers.c:735,737)
+  int rel_change = 0;
+  int print_level = 0;
+  int logging = 0;
+  int precond = MK_PRECOND_NONE;
+  int check_every = 16;
+  // work space (setup)
+  int64_t n = 0;
+  double *r = nullptr, *p = nullptr, *s = nullptr;
+  double *slab1 = nullptr, *slab2 = nullptr;
+  mk::PcgState *state = nullptr;
+  double *norms = nullptr;
+  int norms_cap = 0;
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  // results
+  long long iterations = 0;
+  double rel_res_norm = 0.0;
+  int converged = 0, breakdown = 0;
+};
+
+namespace mk {
+
+static void pcg_release(mk_pcg *S) {
+  dev_free(S->r); dev_free(S->p); dev_free(S->s); dev_free(S->slab1); dev_free(S->slab2);
+  dev_free(S->state); dev_free(S->norms);
+  S->r = S->p = S->s = S->slab1 = S->slab2 = S->norms = nullptr;
+  S->state = nullptr;
+  for (int k = 0; k < 2; k++)
+    if (S->ev[k]) { (void)hipEventDestroy(S->ev[k]); S->ev[k] = nullptr; }
+  S->n = 0;
+}
+
+}  // namespace mk
+
+using namespace mk;
+
+extern "C" {
+
+int mk_pcg_create(mk_pcg **solver) {
+  MK_REQUIRE_INIT();
+  if (!solver) return fail(MK_ERR_INVALID, "mk_pcg_create: null argument");
+  *solver = new mk_pcg();
+  return MK_OK;
+}
+
+#define MK_PCG_SETTER(name, field, type, cond)                                        \
+  int name(mk_pcg *solver, type v) {                                                   \
+    if (!solver) return fail(MK_ERR_INVALID, #name ": null solver");                   \
+    if (!(cond)) return fail(MK_ERR_INVALID, #name ": value out of range");            \
+    solver->field = v;                                                                 \
+    return MK_OK;                                                                      \
+  }
+MK_PCG_SETTER(mk_pcg_set_max_iter, max_iter, int, v >= 0)
+MK_PCG_SETTER(mk_pcg_set_tol, tol, double, v >= 0.0)
+MK_PCG_SETTER(mk_pcg_set_two_norm, two_norm, int, v == 0 || v == 1)
+MK_PCG_SETTER(mk_pcg_set_rel_change, rel_change, int, v == 0 || v == 1)
+MK_PCG_SETTER(mk_pcg_set_print_level, print_level, int, v >= 0)
+MK_PCG_SETTER(mk_pcg_set_logging, logging, int, v >= 0)
+MK_PCG_SETTER(mk_pcg_set_precond, precond, int, v == MK_PRECOND_NONE || v == MK_PRECOND_JACOBI)
+MK_PCG_SETTER(mk_pcg_set_check_every, check_every, int, v >= 1)
+#undef MK_PCG_SETTER
+
+int mk_pcg_setup(mk_pcg *S, const mk_matrix *A, const mk_vector *b, const mk_vector *x) {
+  MK_REQUIRE_INIT();
+  if (!S || !A || !b || !x) return fail(MK_ERR_INVALID, "mk_pcg_setup: null argument");
+  if (A->nrows != A->ncols) return fail(MK_ERR_INVALID, "mk_pcg_setup: matrix is %lld x %lld, must be square", (long long)A->nrows, (long long)A->ncols);
+  if (b->n != A->nrows || x->n != A->nrows) return fail(MK_ERR_INVALID, "mk_pcg_setup: vector length does not match the matrix");
+  pcg_release(S);
+  S->n = A->nrows;
+  MK_TRY(dev_alloc(&S->r, (size_t)S->n));
+  MK_TRY(dev_alloc(&S->p, (size_t)S->n));
+  MK_TRY(dev_alloc(&S->s, (size_t)S->n));
+  MK_TRY(dev_alloc(&S->slab1, (size_t)kMaxParts * kSlabStride));
+  MK_TRY(dev_alloc(&S->slab2, (size_t)kMaxParts * kSlabStride));
+  MK_TRY(dev_alloc(&S->state, 1));
+  if (S->logging > 0 || S->print_level > 0) {
+    S->norms_cap = S->max_iter + 1;
+    MK_TRY(dev_alloc(&S->norms, (size_t)S->norms_cap));
+  }
+  for (int k = 0; k < 2; k++) MK_HIP(hipEventCreateWithFlags(&S->ev[k], hipEventDisableTiming));
+  MK_TRY(analyse_matrix(const_cast<mk_matrix *>(A)));
+  if (S->precond == MK_PRECOND_JACOBI) MK_TRY(ensure_dinv(const_cast<mk_matrix *>(A)));
+  MK_HIP(hipStreamSynchronize(ctx().stream));
+  return MK_OK;
+}
+
+int mk_pcg_solve(mk_pcg *S, const mk_matrix *A, const mk_vector *b, mk_vector *x) {
+  MK_REQUIRE_INIT();
+  if (!S || !A || !b || !x) return fail(MK_ERR_INVALID, "mk_pcg_solve: null argument");
+  if (S->n != A->nrows || !S->state) return fail(MK_ERR_INVALID, "mk_pcg_solve: call mk_pcg_setup with this matrix first");
+  if (b->n != S->n || x->n != S->n) return fail(MK_ERR_INVALID, "mk_pcg_solve: vector length does not match the matrix");
+  if (S->norms && S->norms_cap < S->max_iter + 1) return fail(MK_ERR_INVALID, "mk_pcg_solve: max_iter was raised after setup");
+  if (S->precond == MK_PRECOND_JACOBI && !A->dinv) return fail(MK_ERR_INVALID, "mk_pcg_solve: preconditioner changed after setup");
+  Context &c = ctx();
+  const int64_t n = S->n;
+  const double *dinv = (S->precond == MK_PRECOND_JACOBI) ? A->dinv : nullptr;
+  PcgState *hst = static_cast<PcgState *>(c.pinned);  // two slots
+  S->iterations = 0; S->rel_res_norm = 0.0; S->converged = 0; S->breakdown = 0;
+  if (n == 0) return MK_OK;
+  const int vb = vec_blocks(n);
+
+  // r = b - A x;  p = C r;  gamma = <r,p>;  bi_prod = <b,b>
+  hipLaunchKernelGGL(copy_kernel, dim3(vb), dim3(256), 0, c.stream, S->r, b->d, n);
+  MK_TRY(launch_spmv(A, -1.0, x->d, 1.0, S->r));
+  hipLaunchKernelGGL(pcg_init_vectors_kernel, dim3(vb), dim3(kVecThreads), 0, c.stream, n, b->d, S->r, dinv, S->p, S->two_norm, S->slab2);
+  hipLaunchKernelGGL(pcg_init_scalars_kernel, dim3(1), dim3(kVecThreads), 0, c.stream, S->slab2, vb, S->tol, S->two_norm, S->state, S->norms);
+  MK_HIP(hipMemcpyAsync(&hst[0], S->state, sizeof(PcgState), hipMemcpyDeviceToHost, c.stream));
+  MK_HIP(hipStreamSynchronize(c.stream));
+  if (!(hst[0].bi_prod > 0.0)) {
+    // hypre_PCGSolve: zero right-hand side -> x = b, zero iterations, norm 0
+    hipLaunchKernelGGL(copy_kernel, dim3(vb), dim3(256), 0, c.stream, x->d, b->d, n);
+    MK_HIP(hipStreamSynchronize(c.stream));
+    return MK_OK;
+  }
+
+  int pending = -1;  // slot with a state copy in flight
+  int nchk = 0;
+  bool stop = false;
+  for (int it = 0; it < S->max_iter && !stop; it++) {
+    int nb1 = 0;
+    MK_TRY(launch_spmv_dot(A, S->p, S->s, S->slab1, &S->state->done, &nb1));
+    if (dinv) {
+      hipLaunchKernelGGL((pcg_update_xr_kernel<true>), dim3(vb), dim3(kVecThreads), 0, c.stream, n, S->p, S->s, dinv, x->d, S->r, S->slab1, nb1, S->slab2, S->state);
+      hipLaunchKernelGGL((pcg_update_p_kernel<true>), dim3(vb), dim3(kVecThreads), 0, c.stream, n, S->r, dinv, S->p, S->slab2, vb, S->two_norm, S->rel_change, S->state, S->norms);
+    } else {
+      hipLaunchKernelGGL((pcg_update_xr_kernel<false>), dim3(vb), dim3(kVecThreads), 0, c.stream, n, S->p, S->s, dinv, x->d, S->r, S->slab1, nb1, S->slab2, S->state);
+      hipLaunchKernelGGL((pcg_update_p_kernel<false>), dim3(vb), dim3(kVecThreads), 0, c.stream, n, S->r, dinv, S->p, S->slab2, vb, S->two_norm, S->rel_change, S->state, S->norms);
+    }
+    if ((it + 1) % S->check_every == 0) {
+      const int slot = nchk & 1;
+      // look at the previous checkpoint first: the GPU stays one batch ahead of the host
+      if (pending >= 0) {
+        MK_HIP(hipEventSynchronize(S->ev[pending]));
+        if (hst[pending].done != 0) stop = true;
+      }
+      if (!stop) {
+        MK_HIP(hipMemcpyAsync(&hst[slot], S->state, sizeof(PcgState), hipMemcpyDeviceToHost, c.stream));
+        MK_HIP(hipEventRecord(S->ev[slot], c.stream));
+        pending = slot;
+        nchk++;
+      }
+    }
+  }
+  MK_HIP(hipGetLastError());
+  MK_HIP(hipMemcpyAsync(&hst[0], S->state, sizeof(PcgState), hipMemcpyDeviceToHost, c.stream));
+  MK_HIP(hipStreamSynchronize(c.stream));
+  S->iterations = hst[0].iter;
+  S->converged = hst[0].converged;
+  S->breakdown = hst[0].breakdown;
+  S->rel_res_norm = sqrt(hst[0].i_prod / hst[0].bi_prod);
+  if (S->print_level > 1) {
+    // same three facts HYPRE's print level reports per solve; per-iteration table omitted
+    printf("PCG: %lld iterations, relative residual %e%s\n", S->iterations, S->rel_res_norm,
+           S->converged ? "" : " (not converged)");
+  }
+  return MK_OK;
+}
+
+int mk_pcg_get_num_iterations(const mk_pcg *S, long long *iterations) {
+  if (!S || !iterations) return fail(MK_ERR_INVALID, "mk_pcg_get_num_iterations: null argument");
+  *iterations = S->iterations;
+  return MK_OK;
+}
+
+int mk_pcg_get_final_relative_residual_norm(const mk_pcg *S, double *norm) {
+  if (!S || !norm) return fail(MK_ERR_INVALID, "mk_pcg_get_final_relative_residual_norm: null argument");
+  *norm = S->rel_res_norm;
+  return MK_OK;
+}
+
+int mk_pcg_get_converged(const mk_pcg *S, int *converged, int *breakdown) {
+  if (!S) return fail(MK_ERR_INVALID, "mk_pcg_get_converged: null solver");
+  if (converged) *converged = S->converged;
+  if (breakdown) *breakdown = S->breakdown;
+  return MK_OK;
+}
+
+int mk_pcg_get_residual_history(const mk_pcg *S, double *norms, int capacity) {
+  MK_REQUIRE_INIT();
+  if (!S || !norms || capacity < 0) return fail(MK_ERR_INVALID, "mk_pcg_get_residual_history: bad argument");
+  if (!S->norms) return fail(MK_ERR_INVALID, "mk_pcg_get_residual_history: logging was off at setup");
+  int count = (int)std::min<long long>(S->iterations + 1, capacity);
+  if (S->breakdown == 1 || S->breakdown == 2) count = (int)std::min<long long>(S->iterations, capacity);  // no norm for the aborted step
+  if (count > 0) {
+    MK_HIP(hipMemcpyAsync(norms, S->norms, sizeof(double) * count, hipMemcpyDeviceToHost, ctx().stream));
+    MK_HIP(hipStreamSynchronize(ctx().stream));
+  }
+  return count;
+}
+
+int mk_pcg_destroy(mk_pcg *S) {
+  if (!S) return MK_OK;
+  if (ctx().ready) (void)hipStreamSynchronize(ctx().stream);
+  pcg_release(S);
+  delete S;
+  return MK_OK;
+}
+
+}  // extern "C"
+
+// =========================================================================== Jacobi
+// Extension, solver id 70 (the reference has no Jacobi iteration: SURVEY.md 8a row A11).
+//   x_{k+1} = x_k + D^-1 (b - A x_k), D taken from the row itself while it streams by;
+//   the same pass yields ||b - A x_k||^2, tested every check_every iterations.
+// Algorithmic bytes per iteration: 12*nnz + 28*n.
+namespace mk {
+
+struct JacobiState {
+  double rr, bb, eps;
+  long long iter;
+  int done;
+  int converged;
+};
+
+template <int G>
+__global__ __launch_bounds__(256) void jacobi_step_kernel(int64_t nrows, const int *__restrict__ rowptr,
+                                                           const int *__restrict__ col, const double *__restrict__ val,
+                                                           const double *__restrict__ b, const double *__restrict__ xold,
+                                                           double *__restrict__ xnew, double *__restrict__ slab,
+                                                           const JacobiState *st) {
+  if (st->done != 0) return;
+  constexpr int ROWS = 256 / G;
+  const int g = threadIdx.x % G, rl = threadIdx.x / G;
+  double acc = 0.0;
+  for (int64_t base = (int64_t)blockIdx.x * ROWS; base < nrows; base += (int64_t)gridDim.x * ROWS) {
+    const int64_t row = base + rl;
+    double sum = 0.0, dv = 0.0;
+    int dj = -1;
+    if (row < nrows) {
+      const int bgn = rowptr[row], end = rowptr[row + 1];
+      for (int j = bgn + g; j < end; j += G) {
+        const int cj = col[j];
+        const double vj = val[j];
+        sum += vj * xold[cj];
+        if (cj == (int)row) { dj = j; dv = vj; }   // the last stored diagonal entry wins, as in a serial sweep
+      }
+    }
+#pragma unroll
+    for (int off = G / 2; off > 0; off >>= 1) {
+      sum += __shfl_down(sum, off, G);
+      const int oj = __shfl_down(dj, off, G);
+      const double ov = __shfl_down(dv, off, G);
+      if (oj > dj) { dj = oj; dv = ov; }
+    }
+    if (g == 0 && row < nrows) {
+      const double res = b[row] - sum;
+      acc += res * res;
+      xnew[row] = xold[row] + res / dv;
+    }
+  }
+  __shared__ double smem[256 / 64];
+  double v[1] = {acc};
+  block_sum<1, 256>(v, smem);
+  if (threadIdx.x == 0) slab[blockIdx.x] = v[0];
+}
+
+__global__ __launch_bounds__(256) void jacobi_check_kernel(const double *slab, int nblocks, long long k, JacobiState *st) {
+  if (st->done != 0) return;
+  __shared__ double smem[256 / 64];
+  double v[1];
+  reduce_slab<1, 256>(slab, nblocks, v, smem);
+  if (threadIdx.x == 0) {
+    st->rr = v[0];
+    st->iter = k;
+    if (v[0] / st->bb < st->eps) { st->converged = 1; st->done = 1; }
+  }
+}
+
+__global__ __launch_bounds__(256) void dot_self_kernel(int64_t n, const double *__restrict__ a, double *__restrict__ slab) {
+  double v[1] = {0.0};
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) v[0] += a[i] * a[i];
+  __shared__ double smem[256 / 64];
+  block_sum<1, 256>(v, smem);
+  if (threadIdx.x == 0) slab[blockIdx.x] = v[0];
+}
+
+__global__ __launch_bounds__(256) void jacobi_init_kernel(const double *slab, int nblocks, double tol, JacobiState *st) {
+  __shared__ double smem[256 / 64];
+  double v[1];
+  reduce_slab<1, 256>(slab, nblocks, v, smem);
+  if (threadIdx.x == 0) {
+    JacobiState s;
+    memset(&s, 0, sizeof(s));
+    s.bb = v[0];
+    s.eps = tol * tol;
+    s.done = (v[0] > 0.0) ? 0 : 1;
+    *st = s;
+  }
+}
+
+}  // namespace mk
+
+struct mk_jacobi {
+  int max_iter = 1000;
+  double tol = 1e-6;
+  int check_every = 10;
+  int64_t n = 0;
+  double *xalt = nullptr, *slab = nullptr;
+  mk::JacobiState *state = nullptr;
+  long long iterations = 0;
+  double rel_res_norm = 0.0;
+  int converged = 0;
+};
+
+extern "C" {
+
+int mk_jacobi_create(mk_jacobi **solver) {
+  MK_REQUIRE_INIT();
+  if (!solver) return fail(MK_ERR_INVALID, "mk_jacobi_create: null argument");
+  *solver = new mk_jacobi();
+  return MK_OK;
+}
+int mk_jacobi_set_max_iter(mk_jacobi *S, int v) {
+  if (!S || v < 0) return fail(MK_ERR_INVALID, "mk_jacobi_set_max_iter: bad argument");
+  S->max_iter = v; return MK_OK;
+}
+int mk_jacobi_set_tol(mk_jacobi *S, double v) {
+  if (!S || !(v >= 0.0)) return fail(MK_ERR_INVALID, "mk_jacobi_set_tol: bad argument");
+  S->tol = v; return MK_OK;
+}
+int mk_jacobi_set_check_every(mk_jacobi *S, int v) {
+  if (!S || v < 1) return fail(MK_ERR_INVALID, "mk_jacobi_set_check_every: bad argument");
+  S->check_every = v; return MK_OK;
+}
+
+int mk_jacobi_setup(mk_jacobi *S, const mk_matrix *A, const mk_vector *b, const mk_vector *x) {
+  MK_REQUIRE_INIT();
+  if (!S || !A || !b || !x) return fail(MK_ERR_INVALID, "mk_jacobi_setup: null argument");
+  if (A->nrows != A->ncols) return fail(MK_ERR_INVALID, "mk_jacobi_setup: matrix must be square");
+  if (b->n != A->nrows || x->n != A->nrows) return fail(MK_ERR_INVALID, "mk_jacobi_setup: vector length does not match the matrix");
+  dev_free(S->xalt); dev_free(S->slab); dev_free(S->state);
+  S->xalt = nullptr; S->slab = nullptr; S->state = nullptr;
+  S->n = A->nrows;
+  MK_TRY(dev_alloc(&S->xalt, (size_t)S->n));
+  MK_TRY(dev_alloc(&S->slab, (size_t)kSlabStride));
+  MK_TRY(dev_alloc(&S->state, 1));
+  MK_TRY(analyse_matrix(const_cast<mk_matrix *>(A)));
+  return MK_OK;
+}
+
+int mk_jacobi_solve(mk_jacobi *S, const mk_matrix *A, const mk_vector *b, mk_vector *x) {
+  MK_REQUIRE_INIT();
+  if (!S || !A || !b || !x) return fail(MK_ERR_INVALID, "mk_jacobi_solve: null argument");
+  if (S->n != A->nrows || !S->state) return fail(MK_ERR_INVALID, "mk_jacobi_solve: call mk_jacobi_setup with this matrix first");
+  if (b->n != S->n || x->n != S->n) return fail(MK_ERR_INVALID, "mk_jacobi_solve: vector length does not match the matrix");
+  Context &c = ctx();
+  const int64_t n = S->n;
+  S->iterations = 0; S->rel_res_norm = 0.0; S->converged = 0;
+  if (n == 0) return MK_OK;
+  JacobiState *hst = static_cast<JacobiState *>(c.pinned);
+  const int vb = vec_blocks(n);
+  hipLaunchKernelGGL(dot_self_kernel, dim3(vb), dim3(256), 0, c.stream, n, b->d, S->slab);
+  hipLaunchKernelGGL(jacobi_init_kernel, dim3(1), dim3(256), 0, c.stream, S->slab, vb, S->tol, S->state);
+  MK_HIP(hipMemcpyAsync(hst, S->state, sizeof(JacobiState), hipMemcpyDeviceToHost, c.stream));
+  MK_HIP(hipStreamSynchronize(c.stream));
+  if (!(hst->bb > 0.0)) {
+    hipLaunchKernelGGL(copy_kernel, dim3(vb), dim3(256), 0, c.stream, x->d, b->d, n);
+    MK_HIP(hipStreamSynchronize(c.stream));
+    return MK_OK;
+  }
+  const int G = A->lanes;
+  const int64_t rows_per_block = 256 / G;
+  int blocks = (int)std::min<int64_t>((n + rows_per_block - 1) / rows_per_block, std::min<int64_t>((int64_t)c.num_cus * 8, kSlabStride));
+  double *cur = x->d, *nxt = S->xalt;
+  long long k = 0;
+  int checks = 0;
+  for (;;) {
+#define MK_JSTEP(GG) case GG: hipLaunchKernelGGL((jacobi_step_kernel<GG>), dim3(blocks), dim3(256), 0, c.stream, n, A->rowptr, A->col, A->val, b->d, cur, nxt, S->slab, S->state); break;
+    switch (G) { MK_JSTEP(1) MK_JSTEP(2) MK_JSTEP(4) MK_JSTEP(8) MK_JSTEP(16) MK_JSTEP(32) MK_JSTEP(64)
+      default: return fail(MK_ERR_INVALID, "jacobi: bad lanes per row %d", G); }
+#undef MK_JSTEP
+    const bool last = (k >= S->max_iter);
+    if (k % S->check_every == 0 || last) {
+      hipLaunchKernelGGL(jacobi_check_kernel, dim3(1), dim3(256), 0, c.stream, S->slab, blocks, k, S->state);
+      checks++;
+      // read the flag back every 4th check (and at the end); later steps are no-ops once it is set
+      if (last || checks % 4 == 0) {
+        MK_HIP(hipMemcpyAsync(hst, S->state, sizeof(JacobiState), hipMemcpyDeviceToHost, c.stream));
+        MK_HIP(hipStreamSynchronize(c.stream));
+        if (hst->done != 0 || last) break;
+      }
+    }
+    std::swap(cur, nxt);
+    k++;
+  }
+  MK_HIP(hipGetLastError());
+  // x_k sits in the buffer that was `cur` when iteration hst->iter ran: parity of iter
+  S->iterations = hst->iter;
+  S->converged = hst->converged;
+  S->rel_res_norm = sqrt(hst->rr / hst->bb);
+  if (hst->iter & 1) {  // odd iterate lives in xalt
+    hipLaunchKernelGGL(copy_kernel, dim3(vb), dim3(256), 0, c.stream, x->d, S->xalt, n);
+    MK_HIP(hipStreamSynchronize(c.stream));
+  }
+  return MK_OK;
+}
+
+int mk_jacobi_get_num_iterations(const mk_jacobi *S, long long *iterations) {
+  if (!S || !iterations) return fail(MK_ERR_INVALID, "mk_jacobi_get_num_iterations: null argument");
+  *iterations = S->iterations; return MK_OK;
+}
+int mk_jacobi_get_final_relative_residual_norm(const mk_jacobi *S, double *norm) {
+  if (!S || !norm) return fail(MK_ERR_INVALID, "mk_jacobi_get_final_relative_residual_norm: null argument");
+  *norm = S->rel_res_norm; return MK_OK;
+}
+int mk_jacobi_get_converged(const mk_jacobi *S, int *converged) {
+  if (!S || !converged) return fail(MK_ERR_INVALID, "mk_jacobi_get_converged: null argument");
+  *converged = S->converged; return MK_OK;
+}
+int mk_jacobi_destroy(mk_jacobi *S) {
+  if (!S) return MK_OK;
+  if (ctx().ready) (void)hipStreamSynchronize(ctx().stream);
+  dev_free(S->xalt); dev_free(S->slab); dev_free(S->state);
+  delete S;
+  return MK_OK;
+}
+
+}  // extern "C"

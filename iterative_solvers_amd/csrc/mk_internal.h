@@ -1,0 +1,180 @@
+// mk_internal.h -- shared host/device plumbing of libmi355_krylov.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../include/mk_krylov.h"
+
+namespace mk {
+
+// ----------------------------------------------------------------------------- errors
+void set_error(const char *fmt, ...);
+int fail(int code, const char *fmt, ...);
+
+#define MK_HIP(call)                                                                       \
+  do {                                                                                     \
+    hipError_t e_ = (call);                                                                \
+    if (e_ != hipSuccess)                                                                  \
+      return mk::fail(MK_ERR_HIP, "%s:%d: %s -> %s", __FILE__, __LINE__, #call,            \
+                      hipGetErrorString(e_));                                              \
+  } while (0)
+
+#define MK_TRY(expr)                      \
+  do {                                    \
+    int rc_ = (expr);                     \
+    if (rc_ != MK_OK) return rc_;         \
+  } while (0)
+
+#define MK_REQUIRE_INIT()                                                         \
+  do {                                                                            \
+    if (!mk::ctx().ready) return mk::fail(MK_ERR_NOT_INIT, "mk_init() not called"); \
+  } while (0)
+
+// ---------------------------------------------------------------------------- context
+struct Context {
+  bool ready = false;
+  int device = -1;
+  int num_cus = 256;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // pinned staging for small read-backs (solver state)
+  void *pinned = nullptr;
+  size_t pinned_bytes = 0;
+  // scratch for stand-alone fused calls (mk_spmv_dot): partial slab + 2 results
+  double *slab = nullptr;
+  double *scalars = nullptr;
+};
+Context &ctx();
+
+template <typename T>
+int dev_alloc(T **p, size_t count) {
+  *p = nullptr;
+  if (count == 0) count = 1;  // keep pointers valid for empty objects
+  hipError_t e = hipMalloc(reinterpret_cast<void **>(p), count * sizeof(T));
+  if (e != hipSuccess) return fail(MK_ERR_ALLOC, "hipMalloc(%zu bytes): %s", count * sizeof(T), hipGetErrorString(e));
+  return MK_OK;
+}
+inline void dev_free(void *p) {
+  if (p) (void)hipFree(p);
+}
+
+// ---------------------------------------------------------------------------- objects
+}  // namespace mk
+
+// opaque C types (global namespace, matching the header's forward declarations)
+struct mk_vector {
+  int64_t n = 0;
+  double *d = nullptr;
+};
+
+struct mk_coo {
+  int64_t nrows = 0, ncols = 0, nnz = 0;
+  int *rows = nullptr;
+  int *cols = nullptr;
+  double *vals = nullptr;
+};
+
+struct mk_matrix {
+  int64_t nrows = 0, ncols = 0, nnz = 0;
+  int *rowptr = nullptr;   // nrows+1
+  int *col = nullptr;      // nnz
+  double *val = nullptr;   // nnz
+  double *dinv = nullptr;  // 1/diag, built on demand (Jacobi preconditioner)
+  // selector state
+  mk_matrix_info info{};
+  bool analysed = false;
+  int kernel = MK_SPMV_AUTO;
+  int lanes = 0;
+  // stream kernel: chunk c covers rows [chunk_row[c], chunk_row[c+1])
+  int *chunk_row = nullptr;
+  int nchunks = 0;
+  // long rows (split over several blocks)
+  int *long_rows = nullptr;
+  int n_long = 0;
+};
+
+namespace mk {
+
+// grid-level reduction slabs: component k of block b lives at slab[k * stride + b]
+constexpr int kMaxParts = 4;
+constexpr int kSlabStride = 4096;  // >= any reduction grid we launch
+
+int analyse_matrix(mk_matrix *A);
+int ensure_dinv(mk_matrix *A);
+
+// launchers shared between translation units (all enqueue on ctx().stream)
+// y = alpha*A*x + beta*y
+int launch_spmv(const mk_matrix *A, double alpha, const double *x, double beta, double *y);
+// y = A*x, partial sums of <y,x>,<x,x> into slab (components 0,1); returns blocks used.
+// `done` (may be null) is a device flag: nonzero -> kernel returns at once.
+int launch_spmv_dot(const mk_matrix *A, const double *x, double *y, double *slab, const int *done, int *nblocks);
+
+int exclusive_scan_u32(const uint32_t *in, uint32_t *out, size_t n, uint32_t *total_out_dev);
+
+// device COO -> CSR (stable by row).  Takes ownership of rows/cols/vals buffers of `coo`
+// (they are freed or become the CSR arrays).  sorted_rows_out (optional) receives the
+// sorted row keys (device buffer of nnz ints owned by caller afterwards).
+int device_coo_to_csr(mk_coo *coo, mk_matrix *A, int **sorted_rows_out);
+
+}  // namespace mk
+
+// ------------------------------------------------------------------- device helpers
+#if defined(__HIPCC__)
+namespace mk {
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;  // valid in lane 0
+}
+
+// sum within aligned groups of G lanes (G power of two <= 64); result valid in the group's lane 0
+template <int G>
+__device__ __forceinline__ double group_sum(double v) {
+#pragma unroll
+  for (int off = G / 2; off > 0; off >>= 1) v += __shfl_down(v, off, G);
+  return v;
+}
+
+// Block-wide sums of NP values; every thread gets the totals in out[].  Fixed order:
+// lanes by shuffle tree, then waves 0..nw-1 left to right -> bitwise reproducible.
+template <int NP, int THREADS>
+__device__ __forceinline__ void block_sum(double (&v)[NP], double *smem /* NP*(THREADS/64) */) {
+  constexpr int NW = THREADS / 64;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < NP; k++) {
+    double s = wave_sum(v[k]);
+    if (lane == 0) smem[k * NW + w] = s;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < NP; k++) {
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < NW; i++) s += smem[k * NW + i];
+    v[k] = s;
+  }
+  __syncthreads();
+}
+
+// Sum the per-block partials a previous kernel left in a slab (launch-boundary reduce:
+// no in-launch hand-off, so no fences).  Every block computes the same bits.
+template <int NP, int THREADS>
+__device__ __forceinline__ void reduce_slab(const double *slab, int nblocks, double (&out)[NP], double *smem) {
+#pragma unroll
+  for (int k = 0; k < NP; k++) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += THREADS) s += slab[k * kSlabStride + i];
+    out[k] = s;
+  }
+  block_sum<NP, THREADS>(out, smem);
+}
+
+}  // namespace mk
+#endif

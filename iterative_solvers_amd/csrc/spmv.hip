@@ -1,0 +1,255 @@
+// spmv.hip -- fp64 CSR SpMV kernels for gfx950 and the per-matrix selector.
+//
+// Replaces hypre_ParCSRMatrixMatvec (external to the reference; in-repo stand-in
+// test/sblas_mv_rd.c:51-69).  Bandwidth-bound: 12 B per stored entry + 20 B per row
+// (SURVEY.md 8d), 2 flops per entry -> no MFMA; everything here is about keeping enough
+// independent 64-bit loads in flight and about coalescing.
+//
+//   vector kernel : 2^k lanes of a wave64 share one row (k from the mean row length; k=6 is
+//                   wavefront-per-row).  Lanes of a group read consecutive entries, groups
+//                   read consecutive rows, so a wave's loads of val/col are one contiguous
+//                   span.  Used for short, regular rows (stencils, banded).
+//   stream kernel : nnz-balanced chunks staged through LDS, rows split inside the chunk;
+//                   rows longer than a chunk are split over blocks (skewed / power-law rows).
+#include "mk_internal.h"
+
+namespace mk {
+
+constexpr int kThreads = 256;
+
+// ------------------------------------------------------------------ matrix analysis
+struct AnalysisOut {
+  unsigned long long hist[16];
+  int max_len;
+  int min_len;
+};
+
+__global__ void analyse_rows_kernel(int64_t nrows, const int *__restrict__ rowptr, AnalysisOut *out) {
+  __shared__ unsigned int sh_hist[16];
+  __shared__ int sh_max, sh_min;
+  if (threadIdx.x < 16) sh_hist[threadIdx.x] = 0;
+  if (threadIdx.x == 0) { sh_max = 0; sh_min = 0x7fffffff; }
+  __syncthreads();
+  int lmax = 0, lmin = 0x7fffffff;
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += (int64_t)gridDim.x * blockDim.x) {
+    const int len = rowptr[r + 1] - rowptr[r];
+    int b = (len <= 0) ? 0 : (32 - __clz(len));  // len in [2^(b-1), 2^b)
+    if (b > 15) b = 15;
+    atomicAdd(&sh_hist[b], 1u);
+    lmax = max(lmax, len);
+    lmin = min(lmin, len);
+  }
+  atomicMax(&sh_max, lmax);
+  atomicMin(&sh_min, lmin);
+  __syncthreads();
+  if (threadIdx.x < 16 && sh_hist[threadIdx.x]) atomicAdd(&out->hist[threadIdx.x], (unsigned long long)sh_hist[threadIdx.x]);
+  if (threadIdx.x == 0) { atomicMax(&out->max_len, sh_max); atomicMin(&out->min_len, sh_min); }
+}
+
+__global__ void diag_inverse_kernel(int64_t nrows, const int *__restrict__ rowptr, const int *__restrict__ col,
+                                    const double *__restrict__ val, double *__restrict__ dinv) {
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += (int64_t)gridDim.x * blockDim.x) {
+    double d = 0.0;
+    for (int j = rowptr[r]; j < rowptr[r + 1]; j++)
+      if (col[j] == (int)r) { d = val[j]; break; }
+    dinv[r] = 1.0 / d;  // HYPRE_ParCSRDiagScale divides by the diagonal as stored
+  }
+}
+
+int analyse_matrix(mk_matrix *A) {
+  if (A->analysed) return MK_OK;
+  Context &c = ctx();
+  AnalysisOut *d_out = nullptr, h{};
+  MK_TRY(dev_alloc(&d_out, 1));
+  memset(&h, 0, sizeof(h));
+  h.min_len = 0x7fffffff;
+  MK_HIP(hipMemcpyAsync(d_out, &h, sizeof(h), hipMemcpyHostToDevice, c.stream));
+  if (A->nrows > 0) {
+    int blocks = (int)std::min<int64_t>((A->nrows + 255) / 256, 2048);
+    hipLaunchKernelGGL(analyse_rows_kernel, dim3(blocks), dim3(256), 0, c.stream, A->nrows, A->rowptr, d_out);
+  }
+  MK_HIP(hipMemcpyAsync(&h, d_out, sizeof(h), hipMemcpyDeviceToHost, c.stream));
+  MK_HIP(hipStreamSynchronize(c.stream));
+  dev_free(d_out);
+  mk_matrix_info &I = A->info;
+  I.nrows = A->nrows; I.ncols = A->ncols; I.nnz = A->nnz;
+  I.max_row_len = h.max_len;
+  I.min_row_len = A->nrows ? h.min_len : 0;
+  I.mean_row_len = A->nrows ? (double)A->nnz / (double)A->nrows : 0.0;
+  for (int k = 0; k < 16; k++) I.hist[k] = (int64_t)h.hist[k];
+  // selector: lanes per row = smallest power of two >= mean row length (2..64)
+  int lanes = 2;
+  while (lanes < 64 && (double)lanes < I.mean_row_len) lanes *= 2;
+  if (A->lanes == 0) A->lanes = lanes;
+  if (A->kernel == MK_SPMV_AUTO) A->kernel = MK_SPMV_VECTOR;
+  I.kernel = A->kernel;
+  I.lanes_per_row = A->lanes;
+  I.long_rows = 0;
+  A->analysed = true;
+  return MK_OK;
+}
+
+int ensure_dinv(mk_matrix *A) {
+  if (A->dinv) return MK_OK;
+  MK_TRY(dev_alloc(&A->dinv, (size_t)A->nrows));
+  if (A->nrows) {
+    int blocks = (int)std::min<int64_t>((A->nrows + 255) / 256, 4096);
+    hipLaunchKernelGGL(diag_inverse_kernel, dim3(blocks), dim3(256), 0, ctx().stream, A->nrows, A->rowptr, A->col, A->val, A->dinv);
+    MK_HIP(hipGetLastError());
+  }
+  return MK_OK;
+}
+
+// ------------------------------------------------------------------- vector kernel
+// MODE 0: y = alpha*A*x + beta*y.   MODE 1: y = A*x and per-block partial sums of
+// <y,x> (slab component 0) and <x,x> (component 1) for the CG step.
+template <int G, int MODE>
+__global__ __launch_bounds__(kThreads) void spmv_vector_kernel(
+    int64_t nrows, const int *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ val,
+    const double *__restrict__ x, double *__restrict__ y, double alpha, double beta, double *__restrict__ slab,
+    const int *__restrict__ done) {
+  if (done != nullptr && *done != 0) return;
+  constexpr int ROWS = kThreads / G;
+  const int g = threadIdx.x % G;
+  const int rl = threadIdx.x / G;
+  double acc_yx = 0.0, acc_xx = 0.0;
+  for (int64_t base = (int64_t)blockIdx.x * ROWS; base < nrows; base += (int64_t)gridDim.x * ROWS) {
+    const int64_t row = base + rl;
+    double sum = 0.0;
+    if (row < nrows) {
+      const int b = rowptr[row], e = rowptr[row + 1];
+      for (int j = b + g; j < e; j += G) sum += val[j] * x[col[j]];
+    }
+    sum = group_sum<G>(sum);
+    if (g == 0 && row < nrows) {
+      if (MODE == 0) {
+        y[row] = (beta == 0.0) ? alpha * sum : alpha * sum + beta * y[row];
+      } else {
+        y[row] = sum;
+        const double xr = x[row];
+        acc_yx += sum * xr;
+        acc_xx += xr * xr;
+      }
+    }
+  }
+  if (MODE == 1) {
+    __shared__ double smem[2 * (kThreads / 64)];
+    double v[2] = {acc_yx, acc_xx};
+    block_sum<2, kThreads>(v, smem);
+    if (threadIdx.x == 0) {
+      slab[0 * kSlabStride + blockIdx.x] = v[0];
+      slab[1 * kSlabStride + blockIdx.x] = v[1];
+    }
+  }
+}
+
+template <int MODE>
+static int launch_vector(const mk_matrix *A, double alpha, const double *x, double beta, double *y, double *slab,
+                         const int *done, int *nblocks) {
+  Context &c = ctx();
+  const int G = A->lanes;
+  const int64_t rows_per_block = kThreads / G;
+  int64_t want = (A->nrows + rows_per_block - 1) / rows_per_block;
+  int blocks = (int)std::min<int64_t>(std::max<int64_t>(want, 1), (int64_t)c.num_cus * 8);
+  if (blocks > kSlabStride) blocks = kSlabStride;
+  if (nblocks) *nblocks = blocks;
+#define MK_LAUNCH_G(GG)                                                                                      \
+  case GG:                                                                                                   \
+    hipLaunchKernelGGL((spmv_vector_kernel<GG, MODE>), dim3(blocks), dim3(kThreads), 0, c.stream, A->nrows, \
+                       A->rowptr, A->col, A->val, x, y, alpha, beta, slab, done);                            \
+    break;
+  switch (G) {
+    MK_LAUNCH_G(1)
+    MK_LAUNCH_G(2)
+    MK_LAUNCH_G(4)
+    MK_LAUNCH_G(8)
+    MK_LAUNCH_G(16)
+    MK_LAUNCH_G(32)
+    MK_LAUNCH_G(64)
+    default:
+      return fail(MK_ERR_INVALID, "spmv: lanes per row %d is not a power of two in 1..64", G);
+  }
+#undef MK_LAUNCH_G
+  MK_HIP(hipGetLastError());
+  return MK_OK;
+}
+
+int launch_spmv(const mk_matrix *A, double alpha, const double *x, double beta, double *y) {
+  MK_TRY(analyse_matrix(const_cast<mk_matrix *>(A)));
+  if (A->nrows == 0) return MK_OK;
+  return launch_vector<0>(A, alpha, x, beta, y, nullptr, nullptr, nullptr);
+}
+
+int launch_spmv_dot(const mk_matrix *A, const double *x, double *y, double *slab, const int *done, int *nblocks) {
+  MK_TRY(analyse_matrix(const_cast<mk_matrix *>(A)));
+  return launch_vector<1>(A, 1.0, x, 0.0, y, slab, done, nblocks);
+}
+
+__global__ void finish_dot_kernel(const double *slab, int nblocks, double *out2) {
+  __shared__ double smem[2 * (kThreads / 64)];
+  double v[2];
+  reduce_slab<2, kThreads>(slab, nblocks, v, smem);
+  if (threadIdx.x == 0) { out2[0] = v[0]; out2[1] = v[1]; }
+}
+
+}  // namespace mk
+
+using namespace mk;
+
+extern "C" {
+
+int mk_spmv(const mk_matrix *A, double alpha, const mk_vector *x, double beta, mk_vector *y) {
+  MK_REQUIRE_INIT();
+  if (!A || !x || !y) return fail(MK_ERR_INVALID, "mk_spmv: null argument");
+  if (x->n < A->ncols || y->n < A->nrows)
+    return fail(MK_ERR_INVALID, "mk_spmv: A is %lld x %lld but x has %lld and y has %lld entries",
+                (long long)A->nrows, (long long)A->ncols, (long long)x->n, (long long)y->n);
+  if (x->d == y->d) return fail(MK_ERR_INVALID, "mk_spmv: x and y must not alias");
+  return launch_spmv(A, alpha, x->d, beta, y->d);
+}
+
+int mk_spmv_dot(const mk_matrix *A, const mk_vector *x, mk_vector *y, double *ytx, double *xtx) {
+  MK_REQUIRE_INIT();
+  if (!A || !x || !y) return fail(MK_ERR_INVALID, "mk_spmv_dot: null argument");
+  if (A->nrows != A->ncols) return fail(MK_ERR_INVALID, "mk_spmv_dot: matrix must be square");
+  if (x->n < A->ncols || y->n < A->nrows) return fail(MK_ERR_INVALID, "mk_spmv_dot: vector too short");
+  if (x->d == y->d) return fail(MK_ERR_INVALID, "mk_spmv_dot: x and y must not alias");
+  Context &c = ctx();
+  int nb = 0;
+  MK_TRY(launch_spmv_dot(A, x->d, y->d, c.slab, nullptr, &nb));
+  if (!ytx && !xtx) return MK_OK;  // launch only (timing loops): the partials stay in the slab
+  hipLaunchKernelGGL(finish_dot_kernel, dim3(1), dim3(kThreads), 0, c.stream, c.slab, nb, c.scalars);
+  double h[2] = {0, 0};
+  MK_HIP(hipMemcpyAsync(h, c.scalars, sizeof(h), hipMemcpyDeviceToHost, c.stream));
+  MK_HIP(hipStreamSynchronize(c.stream));
+  if (ytx) *ytx = h[0];
+  if (xtx) *xtx = h[1];
+  return MK_OK;
+}
+
+int mk_matrix_get_info(const mk_matrix *A, mk_matrix_info *info) {
+  MK_REQUIRE_INIT();
+  if (!A || !info) return fail(MK_ERR_INVALID, "mk_matrix_get_info: null argument");
+  MK_TRY(analyse_matrix(const_cast<mk_matrix *>(A)));
+  *info = A->info;
+  return MK_OK;
+}
+
+int mk_matrix_set_spmv_kernel(mk_matrix *A, int kernel, int lanes_per_row) {
+  MK_REQUIRE_INIT();
+  if (!A) return fail(MK_ERR_INVALID, "mk_matrix_set_spmv_kernel: null matrix");
+  MK_TRY(analyse_matrix(A));
+  if (kernel != MK_SPMV_AUTO && kernel != MK_SPMV_VECTOR && kernel != MK_SPMV_STREAM)
+    return fail(MK_ERR_INVALID, "mk_matrix_set_spmv_kernel: unknown kernel %d", kernel);
+  if (lanes_per_row != 0) {
+    if (lanes_per_row < 1 || lanes_per_row > 64 || (lanes_per_row & (lanes_per_row - 1)))
+      return fail(MK_ERR_INVALID, "mk_matrix_set_spmv_kernel: lanes_per_row must be a power of two in 1..64");
+    A->lanes = lanes_per_row;
+  }
+  if (kernel != MK_SPMV_AUTO) A->kernel = kernel;
+  A->info.kernel = A->kernel;
+  A->info.lanes_per_row = A->lanes;
+  return MK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,323 @@
+"""GPU parity tests: every call goes through the C ABI of libmi355_krylov.so and is checked
+against the CPU oracle (oracle/) and the golden fixtures the reference produced.
+Integer/byte results: bit-exact.  SpMV: 1e-12 relative.  CG: iteration count within +-2."""
+import os
+
+import numpy as np
+import pytest
+
+import iterative_solvers_amd as mk
+import oracle
+from conftest import GOLDEN, GOLDEN_CASES
+
+pytestmark = pytest.mark.gpu
+
+SPMV_RTOL = 1e-12   # north_star: "SpMV y matches the reference within 1e-12 relative in fp64"
+CG_ITER_TOL = 2     # north_star: "within +-2 iterations"
+
+
+def _same_bits(a, b):
+    return np.array_equal(np.asarray(a).view(np.uint64), np.asarray(b).view(np.uint64))
+
+
+# ------------------------------------------------------------------ conversion: bit-exact
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_sort_coo_row_golden(name):
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    sr, sc, sv = mk.sort_coo_row(int(g["nrows"]), int(g["ncols"]), g["coo_rows"], g["coo_cols"], g["coo_vals"])
+    assert np.array_equal(sr, g["sorted_rows"])
+    assert np.array_equal(sc, g["sorted_cols"])
+    assert _same_bits(sv, g["sorted_vals"])
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_coo_to_csr_golden(name):
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    rp, ci, v = mk.coo_to_csr(int(g["nrows"]), int(g["ncols"]), g["coo_rows"], g["coo_cols"], g["coo_vals"])
+    assert np.array_equal(rp, g["csr_rowptr"])
+    assert np.array_equal(ci, g["csr_col"])
+    assert _same_bits(v, g["csr_val"])
+
+
+@pytest.mark.parametrize("nrows,nnz,skew", [(1, 100, 0), (3, 50000, 0), (255, 10000, 0), (257, 100000, 0),
+                                            (65536, 300000, 1), (65537, 300000, 0), (1 << 20, 2000000, 1),
+                                            ((1 << 24) + 5, 3000000, 0)])
+def test_coo_to_csr_random_vs_oracle(nrows, nnz, skew):
+    rng = np.random.default_rng(nrows + nnz)
+    if skew:
+        rows = np.minimum((rng.pareto(0.6, nnz)).astype(np.int64), nrows - 1).astype(np.int32)
+    else:
+        rows = rng.integers(0, nrows, nnz).astype(np.int32)
+    cols = rng.integers(0, nrows, nnz).astype(np.int32)
+    vals = rng.normal(size=nnz)
+    rp, ci, v = mk.coo_to_csr(nrows, nrows, rows, cols, vals)
+    orp, oci, ov = oracle.coo_to_csr(nrows, rows, cols, vals)
+    assert np.array_equal(rp, orp) and np.array_equal(ci, oci) and _same_bits(v, ov)
+    sr, sc, sv = mk.sort_coo_row(nrows, nrows, rows, cols, vals)
+    osr, osc, osv = oracle.sort_coo_row(nrows, rows, cols, vals)
+    assert np.array_equal(sr, osr) and np.array_equal(sc, osc) and _same_bits(sv, osv)
+
+
+def test_coo_rejects_bad_indices():
+    with pytest.raises(mk.MkError):
+        mk.coo_to_csr(4, 4, [0, 4], [0, 0], [1.0, 1.0])
+    with pytest.raises(mk.MkError):
+        mk.coo_to_csr(4, 4, [0, 1], [0, -1], [1.0, 1.0])
+
+
+def test_rmat_generator_matches_oracle_and_converts():
+    scale, ne = 12, 1 << 16
+    d = mk.DeviceCOO.rmat(scale, ne, seed=42)
+    nr, nc, r, c, v = d.download()
+    orr, occ, ovv = oracle.rmat_coo(scale, ne, seed=42)
+    assert nr == 1 << scale and np.array_equal(r, orr) and np.array_equal(c, occ) and _same_bits(v, ovv)
+    A = mk.Matrix.from_device_coo(d)
+    rp, ci, val = A.to_csr()
+    orp, oci, ov = oracle.coo_to_csr(nr, orr, occ, ovv)
+    assert np.array_equal(rp, orp) and np.array_equal(ci, oci) and _same_bits(val, ov)
+
+
+# ------------------------------------------------------------------ generators
+@pytest.mark.parametrize("kind,dims", [(5, (37, 19, 1)), (7, (13, 9, 11)), (27, (7, 8, 9)), (27, (1, 1, 5)), (7, (64, 64, 64))])
+def test_stencil_generator(kind, dims):
+    A = mk.Matrix.stencil(kind, *dims)
+    rp, ci, v = A.to_csr()
+    orp, oci, ov = oracle.stencil_csr(kind, *dims)
+    assert np.array_equal(rp, orp) and np.array_equal(ci, oci) and _same_bits(v, ov)
+
+
+def test_stencil_generator_row_block():
+    orp, oci, ov = oracle.stencil_csr(7, 10, 11, 12)
+    A = mk.Matrix.stencil(7, 10, 11, 12, row_begin=333, row_end=999)
+    rp, ci, v = A.to_csr()
+    assert np.array_equal(rp, orp[333:1000] - orp[333])
+    assert np.array_equal(ci, oci[orp[333]:orp[999]]) and _same_bits(v, ov[orp[333]:orp[999]])
+
+
+def test_banded_generator():
+    A = mk.Matrix.banded(5000, 3)
+    rp, ci, v = A.to_csr()
+    orp, oci, ov = oracle.banded_csr(5000, 3)
+    assert np.array_equal(rp, orp) and np.array_equal(ci, oci) and _same_bits(v, ov)
+
+
+# ------------------------------------------------------------------ SpMV
+def _check_spmv(A, rp, ci, v, n, ncols, rng, alpha=1.0, beta=0.0):
+    xh = rng.normal(size=ncols)
+    yh = rng.normal(size=n)
+    x, y = mk.Vector(ncols, values=xh), mk.Vector(n, values=yh)
+    A.spmv(x, y, alpha, beta)
+    got = y.get()
+    ref = oracle.csr_spmv(rp, ci, v, xh, alpha, beta, yh)
+    # scale per row by sum |a_ij x_j| so that cancellation does not hide or fake an error
+    mag = oracle.csr_spmv(rp, ci, np.abs(v), np.abs(xh)) * abs(alpha) + abs(beta) * np.abs(yh)
+    err = np.abs(got - ref) / np.maximum(mag, 1e-300)
+    assert err.max() <= SPMV_RTOL, err.max()
+    assert np.linalg.norm(got - ref) <= SPMV_RTOL * np.linalg.norm(ref) + 1e-300
+
+
+def test_spmv_known_answer():
+    k = np.load(os.path.join(GOLDEN, "sblas_mv_kat.npz"))   # test/sblas_mv_rd.c:15-32
+    A = mk.Matrix.from_csr(5, 7, k["iaptr"], k["iaind"], k["aval"])
+    x, y = mk.Vector(7, values=k["x"]), mk.Vector(5, fill=0.0)
+    A.spmv(x, y)
+    assert np.allclose(y.get(), [3.5, 11.3, 66.9, 21.7, 77.0], rtol=1e-14)
+
+
+@pytest.mark.parametrize("lanes", [1, 2, 4, 8, 16, 32, 64])
+def test_spmv_vector_all_group_widths(lanes):
+    rng = np.random.default_rng(lanes)
+    rp, ci, v = oracle.stencil_csr(27, 9, 10, 11)
+    v = v * rng.uniform(0.5, 1.5, v.size)
+    n = rp.size - 1
+    A = mk.Matrix.from_csr(n, n, rp, ci, v)
+    A.set_spmv_kernel(mk.SPMV_VECTOR, lanes)
+    _check_spmv(A, rp, ci, v, n, n, rng)
+    _check_spmv(A, rp, ci, v, n, n, rng, alpha=-1.0, beta=1.0)
+    _check_spmv(A, rp, ci, v, n, n, rng, alpha=0.5, beta=-2.0)
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_spmv_on_golden_matrices(name):
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    n, nc = int(g["nrows"]), int(g["ncols"])
+    A = mk.Matrix.from_coo(n, nc, g["coo_rows"], g["coo_cols"], g["coo_vals"])
+    _check_spmv(A, g["csr_rowptr"], g["csr_col"], g["csr_val"], n, nc, np.random.default_rng(1))
+
+
+def test_spmv_skewed_rows_rmat():
+    scale, ne = 14, 1 << 18
+    r, c, v = oracle.rmat_coo(scale, ne)
+    n = 1 << scale
+    rp, ci, val = oracle.coo_to_csr(n, r, c, v)
+    A = mk.Matrix.from_coo(n, n, r, c, v)
+    info = A.info()
+    assert info.max_row_len == np.diff(rp).max() and info.nnz == ne
+    assert sum(info.hist) == n and info.hist[0] == np.sum(np.diff(rp) == 0)
+    _check_spmv(A, rp, ci, val, n, n, np.random.default_rng(5))
+
+
+def test_spmv_dot_fused():
+    rp, ci, v = oracle.stencil_csr(7, 20, 21, 22)
+    n = rp.size - 1
+    rng = np.random.default_rng(11)
+    xh = rng.normal(size=n)
+    A = mk.Matrix.from_csr(n, n, rp, ci, v)
+    x, y = mk.Vector(n, values=xh), mk.Vector(n)
+    ytx, xtx = A.spmv_dot(x, y)
+    ref = oracle.csr_spmv(rp, ci, v, xh)
+    assert np.allclose(y.get(), ref, rtol=1e-13, atol=1e-13)
+    assert abs(ytx - ref @ xh) <= 1e-12 * np.abs(ref * xh).sum()
+    assert abs(xtx - xh @ xh) <= 1e-13 * (xh @ xh)
+
+
+def test_spmv_shape_errors():
+    rp, ci, v = oracle.stencil_csr(5, 4, 4)
+    A = mk.Matrix.from_csr(16, 16, rp, ci, v)
+    with pytest.raises(mk.MkError):
+        A.spmv(mk.Vector(15), mk.Vector(16))
+    with pytest.raises(mk.MkError):
+        mk.Matrix.from_csr(16, 16, rp, np.where(ci == 15, 16, ci), v)   # column out of range
+
+
+# ------------------------------------------------------------------ PCG / Jacobi
+@pytest.mark.parametrize("precond", [0, 1])
+@pytest.mark.parametrize("tol", [1e-6, 1e-10])
+def test_pcg_poisson2d_matches_oracle(precond, tol):
+    # config 1 shape, scaled down: 2D 5-point Poisson, b = 1, x0 = 0 (solvers.c:404-426)
+    rp, ci, v = oracle.stencil_csr(5, 96, 96)
+    n = rp.size - 1
+    o = oracle.pcg(rp, ci, v, np.ones(n), tol=tol, precond=precond, maxit=1000, want_norms=True)
+    A = mk.Matrix.from_csr(n, n, rp, ci, v)
+    b, x = mk.Vector(n, fill=1.0), mk.Vector(n, fill=0.0)
+    S = mk.PCG(max_iter=1000, tol=tol, two_norm=1, rel_change=1, precond=precond, logging=1, check_every=7)
+    S.setup(A, b, x)
+    res = S.solve(A, b, x)
+    assert res["converged"] == 1 and o["converged"] == 1
+    assert abs(res["iterations"] - o["iterations"]) <= CG_ITER_TOL
+    assert res["rel_res_norm"] < tol
+    xs = x.get()
+    true_res = np.linalg.norm(np.ones(n) - oracle.csr_spmv(rp, ci, v, xs)) / np.sqrt(n)
+    assert true_res < tol * 1.5
+    assert np.linalg.norm(xs - o["x"]) <= 1e-6 * np.linalg.norm(o["x"])
+    hist = S.residual_history(2000)
+    assert hist.size == res["iterations"] + 1
+    m = min(hist.size, o["rel_norms"].size, 40)
+    assert np.allclose(hist[:m], o["rel_norms"][:m], rtol=1e-8)
+
+
+def test_pcg_3d_jacobi_precond_random_diag():
+    # config 2 shape scaled down; a varying diagonal makes the preconditioner matter
+    rp, ci, v = oracle.stencil_csr(7, 24, 24, 24)
+    n = rp.size - 1
+    rng = np.random.default_rng(2)
+    scale = rng.uniform(1.0, 50.0, n)
+    rows = np.repeat(np.arange(n), np.diff(rp))
+    v = v * np.sqrt(scale[rows] * scale[ci])         # D^1/2 A D^1/2 stays SPD
+    bh = rng.normal(size=n)
+    for precond in (0, 1):
+        o = oracle.pcg(rp, ci, v, bh, tol=1e-8, precond=precond, maxit=2000)
+        A = mk.Matrix.from_csr(n, n, rp, ci, v)
+        b, x = mk.Vector(n, values=bh), mk.Vector(n, fill=0.0)
+        S = mk.PCG(max_iter=2000, tol=1e-8, precond=precond)
+        S.setup(A, b, x)
+        res = S.solve(A, b, x)
+        assert res["converged"] == 1
+        assert abs(res["iterations"] - o["iterations"]) <= CG_ITER_TOL, (res, o["iterations"])
+        assert np.linalg.norm(x.get() - o["x"]) <= 1e-6 * np.linalg.norm(o["x"])
+
+
+def test_pcg_maxit_zero_rhs_and_restart():
+    rp, ci, v = oracle.stencil_csr(5, 40, 40)
+    n = rp.size - 1
+    A = mk.Matrix.from_csr(n, n, rp, ci, v)
+    b, x = mk.Vector(n, fill=1.0), mk.Vector(n, fill=0.0)
+    S = mk.PCG(max_iter=5, tol=1e-12)
+    S.setup(A, b, x)
+    res = S.solve(A, b, x)
+    o = oracle.pcg(rp, ci, v, np.ones(n), tol=1e-12, maxit=5)
+    assert res["iterations"] == 5 and res["converged"] == 0
+    assert np.isclose(res["rel_res_norm"], o["rel_res_norm"], rtol=1e-10)
+    assert np.allclose(x.get(), o["x"], rtol=1e-10)
+    # niter > 1 in the reference re-solves from the previous solution (solvers.c:753-754)
+    res2 = S.solve(A, b, x)
+    o2 = oracle.pcg(rp, ci, v, np.ones(n), x0=o["x"], tol=1e-12, maxit=5)
+    assert np.isclose(res2["rel_res_norm"], o2["rel_res_norm"], rtol=1e-9)
+    # zero right-hand side: hypre returns x = b with zero iterations
+    b0 = mk.Vector(n, fill=0.0)
+    res0 = S.solve(A, b0, x)
+    assert res0["iterations"] == 0 and np.all(x.get() == 0.0)
+
+
+def test_pcg_tol_zero_runs_exactly_maxit():
+    rp, ci, v = oracle.stencil_csr(7, 12, 12, 12)
+    n = rp.size - 1
+    A = mk.Matrix.from_csr(n, n, rp, ci, v)
+    b, x = mk.Vector(n, fill=1.0), mk.Vector(n, fill=0.0)
+    S = mk.PCG(max_iter=20, tol=0.0, check_every=4)
+    S.setup(A, b, x)
+    assert S.solve(A, b, x)["iterations"] == 20
+
+
+@pytest.mark.parametrize("check_every", [1, 5])
+def test_jacobi_banded_matches_oracle(check_every):
+    # config 5 shape scaled down
+    n = 20000
+    rp, ci, v = oracle.banded_csr(n, 3)
+    o = oracle.jacobi(rp, ci, v, np.ones(n), tol=1e-9, maxit=400, check_every=check_every)
+    A = mk.Matrix.banded(n, 3)
+    b, x = mk.Vector(n, fill=1.0), mk.Vector(n, fill=0.0)
+    S = mk.Jacobi(max_iter=400, tol=1e-9, check_every=check_every)
+    S.setup(A, b, x)
+    res = S.solve(A, b, x)
+    assert res["converged"] == 1 == o["converged"]
+    assert res["iterations"] == o["iterations"]
+    assert np.isclose(res["rel_res_norm"], o["rel_res_norm"], rtol=1e-9)
+    assert np.allclose(x.get(), o["x"], rtol=1e-12, atol=0)
+
+
+def test_jacobi_hits_maxit():
+    rp, ci, v = oracle.stencil_csr(5, 30, 30)   # weakly dominant: converges slowly
+    n = rp.size - 1
+    o = oracle.jacobi(rp, ci, v, np.ones(n), tol=1e-12, maxit=37, check_every=10)
+    A = mk.Matrix.from_csr(n, n, rp, ci, v)
+    b, x = mk.Vector(n, fill=1.0), mk.Vector(n, fill=0.0)
+    S = mk.Jacobi(max_iter=37, tol=1e-12, check_every=10)
+    S.setup(A, b, x)
+    res = S.solve(A, b, x)
+    assert res["converged"] == 0 and res["iterations"] == 37 == o["iterations"]
+    assert np.allclose(x.get(), o["x"], rtol=1e-12)
+
+
+# ------------------------------------------------------------------ full-size properties
+def test_full_size_config2_properties():
+    """BASELINE config 2 at full size (7-pt 256^3): the oracle would take minutes, so check
+    size-independent properties: A*1 = boundary deficit (row sums), symmetry <Ax,y> = <x,Ay>,
+    linearity, and that CG reduces the true residual."""
+    nx = 256
+    A = mk.Matrix.stencil(7, nx, nx, nx)
+    n = nx ** 3
+    assert A.nnz == 7 * n - 6 * nx * nx
+    ones, y = mk.Vector(n, fill=1.0), mk.Vector(n)
+    ytx, xtx = A.spmv_dot(ones, y)
+    # sum of all row sums = 6n - (number of neighbour links) = 6 nx^2 missing links
+    assert ytx == 6.0 * nx * nx and xtx == float(n)
+    yh = y.get()
+    assert yh.min() == 0.0 and yh.max() == 3.0 and yh[0] == 3.0 and yh[n // 2 + nx // 2 * nx + nx // 2] == 0.0
+    rng = np.random.default_rng(0)
+    u, w = rng.normal(size=n), rng.normal(size=n)
+    U, W, AU, AW = mk.Vector(n, values=u), mk.Vector(n, values=w), mk.Vector(n), mk.Vector(n)
+    A.spmv(U, AU)
+    A.spmv(W, AW)
+    au, aw = AU.get(), AW.get()
+    assert abs(au @ w - u @ aw) <= 1e-11 * (np.abs(au) @ np.abs(w))
+    A.spmv(U, AW, alpha=2.0, beta=-1.0)          # AW <- 2 A u - A w
+    assert np.allclose(AW.get(), 2.0 * au - aw, rtol=1e-13, atol=1e-12)
+    b, x = mk.Vector(n, fill=1.0), mk.Vector(n, fill=0.0)
+    S = mk.PCG(max_iter=50, tol=0.0, precond=1)
+    S.setup(A, b, x)
+    res = S.solve(A, b, x)
+    assert res["iterations"] == 50
+    A.spmv(x, y)
+    true_rel = np.linalg.norm(1.0 - y.get()) / np.sqrt(n)
+    assert np.isclose(true_rel, res["rel_res_norm"], rtol=1e-6) and true_rel < 0.2
