@@ -55,7 +55,8 @@ template <typename T>
 int dev_alloc(T **p, size_t count) {
   *p = nullptr;
   if (count == 0) count = 1;  // keep pointers valid for empty objects
-  hipError_t e = hipMalloc(reinterpret_cast<void **>(p), count * sizeof(T));
+  // 256 B of slack: the LDS-staged kernels read whole 16-byte vectors around a chunk
+  hipError_t e = hipMalloc(reinterpret_cast<void **>(p), count * sizeof(T) + 256);
   if (e != hipSuccess) return fail(MK_ERR_ALLOC, "hipMalloc(%zu bytes): %s", count * sizeof(T), hipGetErrorString(e));
   return MK_OK;
 }
@@ -90,7 +91,9 @@ struct mk_matrix {
   bool analysed = false;
   int kernel = MK_SPMV_AUTO;
   int lanes = 0;
-  // stream kernel: chunk c covers rows [chunk_row[c], chunk_row[c+1])
+  // stream kernel (fixed rows per chunk): lanes per row and LDS capacity in entries
+  int stream_lanes = 0;
+  int stream_cap = 0;
   int *chunk_row = nullptr;
   int nchunks = 0;
   // long rows (split over several blocks)

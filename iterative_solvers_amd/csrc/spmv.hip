@@ -16,6 +16,7 @@
 namespace mk {
 
 constexpr int kThreads = 256;
+constexpr int kStreamMaxCap = 3072;   // LDS entries per block (12 B each): 36 KB -> 4 blocks per CU
 
 // ------------------------------------------------------------------ matrix analysis
 struct AnalysisOut {
@@ -81,7 +82,16 @@ int analyse_matrix(mk_matrix *A) {
   int lanes = 2;
   while (lanes < 64 && (double)lanes < I.mean_row_len) lanes *= 2;
   if (A->lanes == 0) A->lanes = lanes;
-  if (A->kernel == MK_SPMV_AUTO) A->kernel = MK_SPMV_VECTOR;
+  // stream kernel: 256/G rows per chunk, G lanes per row in the row pass; usable when the
+  // longest row times the rows per chunk fits the LDS budget (regular matrices)
+  int sl = 1;
+  while (sl < 64 && (double)sl * 8.0 < I.mean_row_len) sl *= 2;
+  while (sl < 64 && (int64_t)(kThreads / sl) * I.max_row_len > kStreamMaxCap) sl *= 2;
+  A->stream_lanes = sl;
+  A->stream_cap = (int)((std::max<int64_t>(64, (int64_t)(kThreads / sl) * I.max_row_len) + 3) & ~(int64_t)3);
+  const bool stream_ok = A->stream_cap <= kStreamMaxCap;
+  if (A->kernel == MK_SPMV_AUTO) A->kernel = stream_ok ? MK_SPMV_STREAM : MK_SPMV_VECTOR;
+  if (A->kernel == MK_SPMV_STREAM && !stream_ok) A->kernel = MK_SPMV_VECTOR;
   I.kernel = A->kernel;
   I.lanes_per_row = A->lanes;
   I.long_rows = 0;
@@ -174,14 +184,126 @@ static int launch_vector(const mk_matrix *A, double alpha, const double *x, doub
   return MK_OK;
 }
 
+// ------------------------------------------------------------------- stream kernel
+// Chunk = 256/G consecutive rows.  Pass 1 copies the chunk's val/col spans into LDS with
+// 16-byte loads (coalesced whatever the row lengths are); pass 2 gives every row G lanes
+// that walk the row out of LDS and gather x.  With G=1 (rows up to ~8 entries) lanes of a
+// wave own consecutive rows, so the k-th gather of a stencil row is 64 consecutive x
+// entries, and each row is summed left to right exactly as the serial reference does.
+// Blocks that share an XCD (blockIdx % 8) take a contiguous range of chunks, so the x
+// entries that neighbouring rows share are served by that XCD's L2.
+template <int G, int MODE>
+__global__ __launch_bounds__(kThreads) void spmv_stream_kernel(
+    int64_t nrows, const int *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ val,
+    const double *__restrict__ x, double *__restrict__ y, double alpha, double beta, double *__restrict__ slab,
+    const int *__restrict__ done, int cap) {
+  if (done != nullptr && *done != 0) return;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  double *sval = reinterpret_cast<double *>(smem_raw);                     // cap + 2 doubles
+  int *scol = reinterpret_cast<int *>(smem_raw + (size_t)(cap + 2) * 8);   // cap + 8 ints
+  constexpr int R = kThreads / G;
+  const int tid = threadIdx.x;
+  const int g = tid % G, rl = tid / G;
+  const int64_t nchunks = (nrows + R - 1) / R;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
+  const int64_t per_xcd = (nchunks + 7) / 8;
+  const int64_t first = xcd * per_xcd, last = min(first + per_xcd, nchunks);
+  double acc_yx = 0.0, acc_xx = 0.0;
+  for (int64_t chunk = first + slot; chunk < last; chunk += slots) {
+    const int64_t r0 = chunk * R;
+    const int64_t r1 = min(r0 + R, nrows);
+    const int cb = rowptr[r0], ce = rowptr[r1];
+    const int vb = cb & ~1, ib = cb & ~3;
+    for (int k = vb + tid * 2; k < ce; k += kThreads * 2)
+      *reinterpret_cast<double2 *>(sval + (k - vb)) = *reinterpret_cast<const double2 *>(val + k);
+    for (int k = ib + tid * 4; k < ce; k += kThreads * 4)
+      *reinterpret_cast<int4 *>(scol + (k - ib)) = *reinterpret_cast<const int4 *>(col + k);
+    __syncthreads();
+    const int64_t row = r0 + rl;
+    double sum = 0.0;
+    if (row < r1) {
+      const int b = rowptr[row] - cb, e = rowptr[row + 1] - cb;
+      const double *sv = sval + (cb - vb);
+      const int *sc = scol + (cb - ib);
+      const int lastj = e - 1;
+      for (int j = b + g; j < e; j += 4 * G) {
+        const int j1 = min(j + G, lastj), j2 = min(j + 2 * G, lastj), j3 = min(j + 3 * G, lastj);
+        const int c0 = sc[j], c1 = sc[j1], c2 = sc[j2], c3 = sc[j3];
+        const double x0 = x[c0], x1 = x[c1], x2 = x[c2], x3 = x[c3];
+        const double v0 = sv[j], v1 = sv[j1], v2 = sv[j2], v3 = sv[j3];
+        sum += v0 * x0;
+        if (j + G < e) sum += v1 * x1;
+        if (j + 2 * G < e) sum += v2 * x2;
+        if (j + 3 * G < e) sum += v3 * x3;
+      }
+    }
+    if (G > 1) sum = group_sum<G>(sum);
+    if (g == 0 && row < r1) {
+      if (MODE == 0) {
+        y[row] = (beta == 0.0) ? alpha * sum : alpha * sum + beta * y[row];
+      } else {
+        y[row] = sum;
+        const double xr = x[row];
+        acc_yx += sum * xr;
+        acc_xx += xr * xr;
+      }
+    }
+    __syncthreads();
+  }
+  if (MODE == 1) {
+    double *red = reinterpret_cast<double *>(smem_raw);
+    double v[2] = {acc_yx, acc_xx};
+    block_sum<2, kThreads>(v, red);
+    if (threadIdx.x == 0) {
+      slab[0 * kSlabStride + blockIdx.x] = v[0];
+      slab[1 * kSlabStride + blockIdx.x] = v[1];
+    }
+  }
+}
+
+template <int MODE>
+static int launch_stream(const mk_matrix *A, double alpha, const double *x, double beta, double *y, double *slab,
+                         const int *done, int *nblocks) {
+  Context &c = ctx();
+  const int G = A->stream_lanes, cap = A->stream_cap;
+  const size_t lds = (size_t)(cap + 2) * 8 + (size_t)(cap + 8) * 4;  // cap is a multiple of 4
+  const int64_t nchunks = (A->nrows + (kThreads / G) - 1) / (kThreads / G);
+  int per_cu = (int)std::min<size_t>(8, (size_t)(160 * 1024) / (lds + 512));
+  int64_t blocks = std::min<int64_t>((nchunks + 7) / 8 * 8, (int64_t)c.num_cus * per_cu);
+  blocks = std::max<int64_t>(8, blocks / 8 * 8);
+  if (blocks > kSlabStride) blocks = kSlabStride;
+  if (nblocks) *nblocks = (int)blocks;
+#define MK_LAUNCH_S(GG)                                                                                          \
+  case GG:                                                                                                       \
+    hipLaunchKernelGGL((spmv_stream_kernel<GG, MODE>), dim3((unsigned)blocks), dim3(kThreads), lds, c.stream,  \
+                       A->nrows, A->rowptr, A->col, A->val, x, y, alpha, beta, slab, done, cap);                 \
+    break;
+  switch (G) {
+    MK_LAUNCH_S(1)
+    MK_LAUNCH_S(2)
+    MK_LAUNCH_S(4)
+    MK_LAUNCH_S(8)
+    MK_LAUNCH_S(16)
+    MK_LAUNCH_S(32)
+    MK_LAUNCH_S(64)
+    default:
+      return fail(MK_ERR_INVALID, "spmv: stream lanes per row %d invalid", G);
+  }
+#undef MK_LAUNCH_S
+  MK_HIP(hipGetLastError());
+  return MK_OK;
+}
+
 int launch_spmv(const mk_matrix *A, double alpha, const double *x, double beta, double *y) {
   MK_TRY(analyse_matrix(const_cast<mk_matrix *>(A)));
   if (A->nrows == 0) return MK_OK;
+  if (A->kernel == MK_SPMV_STREAM) return launch_stream<0>(A, alpha, x, beta, y, nullptr, nullptr, nullptr);
   return launch_vector<0>(A, alpha, x, beta, y, nullptr, nullptr, nullptr);
 }
 
 int launch_spmv_dot(const mk_matrix *A, const double *x, double *y, double *slab, const int *done, int *nblocks) {
   MK_TRY(analyse_matrix(const_cast<mk_matrix *>(A)));
+  if (A->kernel == MK_SPMV_STREAM) return launch_stream<1>(A, 1.0, x, 0.0, y, slab, done, nblocks);
   return launch_vector<1>(A, 1.0, x, 0.0, y, slab, done, nblocks);
 }
 
@@ -246,6 +368,9 @@ int mk_matrix_set_spmv_kernel(mk_matrix *A, int kernel, int lanes_per_row) {
       return fail(MK_ERR_INVALID, "mk_matrix_set_spmv_kernel: lanes_per_row must be a power of two in 1..64");
     A->lanes = lanes_per_row;
   }
+  if (kernel == MK_SPMV_STREAM && A->stream_cap > kStreamMaxCap)
+    return fail(MK_ERR_UNSUPPORTED, "mk_matrix_set_spmv_kernel: rows too long for the stream kernel (needs %d LDS entries, limit %d)",
+                A->stream_cap, kStreamMaxCap);
   if (kernel != MK_SPMV_AUTO) A->kernel = kernel;
   A->info.kernel = A->kernel;
   A->info.lanes_per_row = A->lanes;

@@ -137,6 +137,41 @@ def test_spmv_vector_all_group_widths(lanes):
     _check_spmv(A, rp, ci, v, n, n, rng, alpha=0.5, beta=-2.0)
 
 
+@pytest.mark.parametrize("kind,dims", [(5, (33, 17, 1)), (7, (19, 11, 13)), (27, (9, 10, 11)), (7, (70, 70, 70))])
+def test_spmv_stream_kernel_stencils(kind, dims):
+    rng = np.random.default_rng(kind)
+    rp, ci, v = oracle.stencil_csr(kind, *dims)
+    v = v * rng.uniform(0.5, 1.5, v.size)
+    n = rp.size - 1
+    A = mk.Matrix.from_csr(n, n, rp, ci, v)
+    assert A.info().kernel == mk.SPMV_STREAM          # regular rows -> LDS-staged kernel
+    _check_spmv(A, rp, ci, v, n, n, rng)
+    _check_spmv(A, rp, ci, v, n, n, rng, alpha=-1.0, beta=1.0)
+    if kind != 27:
+        # one lane per row sums left to right like the serial reference: same bits
+        xh = rng.normal(size=n)
+        x, y = mk.Vector(n, values=xh), mk.Vector(n)
+        A.spmv(x, y)
+        assert np.array_equal(y.get(), oracle.csr_spmv(rp, ci, v, xh))
+    A.set_spmv_kernel(mk.SPMV_VECTOR)
+    _check_spmv(A, rp, ci, v, n, n, rng)
+
+
+def test_spmv_stream_ragged_rows():
+    # rows of very different lengths incl. empty ones, chunk spans not 16-byte aligned
+    rng = np.random.default_rng(9)
+    n = 3001
+    lens = rng.integers(0, 12, n)
+    lens[rng.random(n) < 0.2] = 0
+    rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    ci = rng.integers(0, n, rp[-1]).astype(np.int32)
+    v = rng.normal(size=rp[-1])
+    A = mk.Matrix.from_csr(n, n, rp, ci, v)
+    for lanes_kernel in (mk.SPMV_STREAM, mk.SPMV_VECTOR):
+        A.set_spmv_kernel(lanes_kernel)
+        _check_spmv(A, rp, ci, v, n, n, rng, alpha=1.5, beta=0.25)
+
+
 @pytest.mark.parametrize("name", GOLDEN_CASES)
 def test_spmv_on_golden_matrices(name):
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
