@@ -16,7 +16,7 @@
 namespace mk {
 
 constexpr int kThreads = 256;
-constexpr int kStreamMaxCap = 3072;   // LDS entries per block (12 B each): 36 KB -> 4 blocks per CU
+constexpr int kStreamMaxCap = 3064;   // LDS entries per block (12 B each): 36 KB -> 4 blocks per CU
 
 // ------------------------------------------------------------------ matrix analysis
 struct AnalysisOut {
@@ -192,7 +192,15 @@ static int launch_vector(const mk_matrix *A, double alpha, const double *x, doub
 // entries, and each row is summed left to right exactly as the serial reference does.
 // Blocks that share an XCD (blockIdx % 8) take a contiguous range of chunks, so the x
 // entries that neighbouring rows share are served by that XCD's L2.
-template <int G, int MODE>
+typedef double d2_t __attribute__((ext_vector_type(2)));
+typedef int i4_t __attribute__((ext_vector_type(4)));
+
+// U = LDS capacity class: cap <= 1024*U - 8 entries, so a thread stages at most 2U 16-byte
+// val loads and U 16-byte col loads per chunk.  The loads of chunk k+1 are issued between
+// the x gathers of chunk k and their first use, so they stay in flight through pass 2 and
+// the barrier (loads retire in order: anything issued BEFORE the gathers would be waited
+// for with them).
+template <int G, int MODE, int U>
 __global__ __launch_bounds__(kThreads) void spmv_stream_kernel(
     int64_t nrows, const int *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ val,
     const double *__restrict__ x, double *__restrict__ y, double alpha, double beta, double *__restrict__ slab,
@@ -202,6 +210,7 @@ __global__ __launch_bounds__(kThreads) void spmv_stream_kernel(
   double *sval = reinterpret_cast<double *>(smem_raw);                     // cap + 2 doubles
   int *scol = reinterpret_cast<int *>(smem_raw + (size_t)(cap + 2) * 8);   // cap + 8 ints
   constexpr int R = kThreads / G;
+  constexpr int NV = 2 * U, NI = U;
   const int tid = threadIdx.x;
   const int g = tid % G, rl = tid / G;
   const int64_t nchunks = (nrows + R - 1) / R;
@@ -209,46 +218,94 @@ __global__ __launch_bounds__(kThreads) void spmv_stream_kernel(
   const int64_t per_xcd = (nchunks + 7) / 8;
   const int64_t first = xcd * per_xcd, last = min(first + per_xcd, nchunks);
   double acc_yx = 0.0, acc_xx = 0.0;
-  for (int64_t chunk = first + slot; chunk < last; chunk += slots) {
-    const int64_t r0 = chunk * R;
-    const int64_t r1 = min(r0 + R, nrows);
-    const int cb = rowptr[r0], ce = rowptr[r1];
-    const int vb = cb & ~1, ib = cb & ~3;
-    for (int k = vb + tid * 2; k < ce; k += kThreads * 2)
-      *reinterpret_cast<double2 *>(sval + (k - vb)) = *reinterpret_cast<const double2 *>(val + k);
-    for (int k = ib + tid * 4; k < ce; k += kThreads * 4)
-      *reinterpret_cast<int4 *>(scol + (k - ib)) = *reinterpret_cast<const int4 *>(col + k);
-    __syncthreads();
-    const int64_t row = r0 + rl;
-    double sum = 0.0;
-    if (row < r1) {
-      const int b = rowptr[row] - cb, e = rowptr[row + 1] - cb;
-      const double *sv = sval + (cb - vb);
-      const int *sc = scol + (cb - ib);
-      const int lastj = e - 1;
-      for (int j = b + g; j < e; j += 4 * G) {
-        const int j1 = min(j + G, lastj), j2 = min(j + 2 * G, lastj), j3 = min(j + 3 * G, lastj);
-        const int c0 = sc[j], c1 = sc[j1], c2 = sc[j2], c3 = sc[j3];
-        const double x0 = x[c0], x1 = x[c1], x2 = x[c2], x3 = x[c3];
-        const double v0 = sv[j], v1 = sv[j1], v2 = sv[j2], v3 = sv[j3];
-        sum += v0 * x0;
-        if (j + G < e) sum += v1 * x1;
-        if (j + 2 * G < e) sum += v2 * x2;
-        if (j + 3 * G < e) sum += v3 * x3;
-      }
+
+  d2_t rv[NV];
+  i4_t ri[NI];
+  int64_t chunk = first + slot;
+  int cb = 0, ce = 0;
+  int64_t r0 = 0, r1 = 0;
+  auto stage_loads = [&](int cb_, int ce_) {
+    const int vb_ = cb_ & ~1, ib_ = cb_ & ~3;
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+      const int k = vb_ + (tid + i * kThreads) * 2;
+      if (k < ce_) rv[i] = *reinterpret_cast<const d2_t *>(val + k);
     }
+#pragma unroll
+    for (int i = 0; i < NI; i++) {
+      const int k = ib_ + (tid + i * kThreads) * 4;
+      if (k < ce_) ri[i] = *reinterpret_cast<const i4_t *>(col + k);
+    }
+  };
+  if (chunk < last) {
+    r0 = chunk * R;
+    r1 = min(r0 + R, nrows);
+    cb = rowptr[r0];
+    ce = rowptr[r1];
+    stage_loads(cb, ce);
+  }
+  while (chunk < last) {
+    const int vb = cb & ~1, ib = cb & ~3;
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+      const int k = vb + (tid + i * kThreads) * 2;
+      if (k < ce) *reinterpret_cast<d2_t *>(sval + (k - vb)) = rv[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NI; i++) {
+      const int k = ib + (tid + i * kThreads) * 4;
+      if (k < ce) *reinterpret_cast<i4_t *>(scol + (k - ib)) = ri[i];
+    }
+    const int64_t row = r0 + rl;
+    const bool have_row = row < r1;
+    int b = 0, e = 0;
+    if (have_row) { b = rowptr[row] - cb; e = rowptr[row + 1] - cb; }
+    __syncthreads();
+    const double *sv = sval + (cb - vb);
+    const int *sc = scol + (cb - ib);
+    // first 8 entries of the row (per lane): all gathers issued before anything waits
+    const int lastj = max(e - 1, 0);
+    int cj[8];
+    double xj[8], vj[8];
+    const bool any = have_row && (b + g < e);
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+      const int j = min(b + g + t * G, lastj);
+      cj[t] = any ? sc[j] : 0;
+      vj[t] = any ? sv[j] : 0.0;
+    }
+#pragma unroll
+    for (int t = 0; t < 8; t++) xj[t] = any ? x[cj[t]] : 0.0;
+    const double xr = (MODE == 1 && g == 0 && have_row) ? x[row] : 0.0;
+    const double yold = (MODE == 0 && g == 0 && have_row && beta != 0.0) ? y[row] : 0.0;
+    // prefetch the next chunk (stays in flight while this one is reduced)
+    const int64_t next = chunk + slots;
+    int ncb = 0, nce = 0;
+    int64_t nr0 = 0, nr1 = 0;
+    if (next < last) {
+      nr0 = next * R;
+      nr1 = min(nr0 + R, nrows);
+      ncb = rowptr[nr0];
+      nce = rowptr[nr1];
+      stage_loads(ncb, nce);
+    }
+    double sum = 0.0;
+#pragma unroll
+    for (int t = 0; t < 8; t++)
+      if (have_row && b + g + t * G < e) sum += vj[t] * xj[t];
+    for (int j = b + g + 8 * G; j < e; j += G) sum += sv[j] * x[sc[j]];   // rows longer than 8 lanes' worth
     if (G > 1) sum = group_sum<G>(sum);
-    if (g == 0 && row < r1) {
+    if (g == 0 && have_row) {
       if (MODE == 0) {
-        y[row] = (beta == 0.0) ? alpha * sum : alpha * sum + beta * y[row];
+        y[row] = (beta == 0.0) ? alpha * sum : alpha * sum + beta * yold;
       } else {
         y[row] = sum;
-        const double xr = x[row];
         acc_yx += sum * xr;
         acc_xx += xr * xr;
       }
     }
     __syncthreads();
+    chunk = next; cb = ncb; ce = nce; r0 = nr0; r1 = nr1;
   }
   if (MODE == 1) {
     double *red = reinterpret_cast<double *>(smem_raw);
@@ -261,22 +318,32 @@ __global__ __launch_bounds__(kThreads) void spmv_stream_kernel(
   }
 }
 
-template <int MODE>
-static int launch_stream(const mk_matrix *A, double alpha, const double *x, double beta, double *y, double *slab,
-                         const int *done, int *nblocks) {
+template <int MODE, int U>
+static int launch_stream_u(const mk_matrix *A, double alpha, const double *x, double beta, double *y, double *slab,
+                           const int *done, int *nblocks) {
   Context &c = ctx();
   const int G = A->stream_lanes, cap = A->stream_cap;
   const size_t lds = (size_t)(cap + 2) * 8 + (size_t)(cap + 8) * 4;  // cap is a multiple of 4
   const int64_t nchunks = (A->nrows + (kThreads / G) - 1) / (kThreads / G);
-  int per_cu = (int)std::min<size_t>(8, (size_t)(160 * 1024) / (lds + 512));
+  // resident blocks per CU for this instantiation (registers + LDS), so the grid is one full wave of blocks
+  static const int env_bpc = getenv("MK_STREAM_BPC") ? atoi(getenv("MK_STREAM_BPC")) : 0;
+  int per_cu = env_bpc;
+  if (per_cu <= 0) {
+    int occ = 0;
+    hipError_t oe = hipErrorInvalidValue;
+#define MK_OCC_S(GG) case GG: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, spmv_stream_kernel<GG, MODE, U>, kThreads, lds); break;
+    switch (G) { MK_OCC_S(1) MK_OCC_S(2) MK_OCC_S(4) MK_OCC_S(8) MK_OCC_S(16) MK_OCC_S(32) MK_OCC_S(64) default: break; }
+#undef MK_OCC_S
+    per_cu = (oe == hipSuccess && occ > 0) ? std::min(occ, 8) : 4;
+  }
   int64_t blocks = std::min<int64_t>((nchunks + 7) / 8 * 8, (int64_t)c.num_cus * per_cu);
   blocks = std::max<int64_t>(8, blocks / 8 * 8);
   if (blocks > kSlabStride) blocks = kSlabStride;
   if (nblocks) *nblocks = (int)blocks;
-#define MK_LAUNCH_S(GG)                                                                                          \
-  case GG:                                                                                                       \
-    hipLaunchKernelGGL((spmv_stream_kernel<GG, MODE>), dim3((unsigned)blocks), dim3(kThreads), lds, c.stream,  \
-                       A->nrows, A->rowptr, A->col, A->val, x, y, alpha, beta, slab, done, cap);                 \
+#define MK_LAUNCH_S(GG)                                                                                            \
+  case GG:                                                                                                         \
+    hipLaunchKernelGGL((spmv_stream_kernel<GG, MODE, U>), dim3((unsigned)blocks), dim3(kThreads), lds, c.stream,  \
+                       A->nrows, A->rowptr, A->col, A->val, x, y, alpha, beta, slab, done, cap);                   \
     break;
   switch (G) {
     MK_LAUNCH_S(1)
@@ -292,6 +359,16 @@ static int launch_stream(const mk_matrix *A, double alpha, const double *x, doub
 #undef MK_LAUNCH_S
   MK_HIP(hipGetLastError());
   return MK_OK;
+}
+
+template <int MODE>
+static int launch_stream(const mk_matrix *A, double alpha, const double *x, double beta, double *y, double *slab,
+                         const int *done, int *nblocks) {
+  const int cap = A->stream_cap;
+  if (cap <= 1024 * 1 - 8) return launch_stream_u<MODE, 1>(A, alpha, x, beta, y, slab, done, nblocks);
+  if (cap <= 1024 * 2 - 8) return launch_stream_u<MODE, 2>(A, alpha, x, beta, y, slab, done, nblocks);
+  if (cap <= 1024 * 3 - 8) return launch_stream_u<MODE, 3>(A, alpha, x, beta, y, slab, done, nblocks);
+  return fail(MK_ERR_UNSUPPORTED, "spmv: stream capacity %d too large", cap);
 }
 
 int launch_spmv(const mk_matrix *A, double alpha, const double *x, double beta, double *y) {
