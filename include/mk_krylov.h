@@ -173,6 +173,34 @@ int mk_jacobi_get_final_relative_residual_norm(const mk_jacobi *solver, double *
 int mk_jacobi_get_converged(const mk_jacobi *solver, int *converged);
 int mk_jacobi_destroy(mk_jacobi *solver);
 
+/* ---- row-block distribution over GPUs: one rank per GPU per process, RCCL over xGMI ---------
+ * Stands in for the MPI side of the reference: the row-block split of solvers.c:214-281, the
+ * HYPRE ParCSR diag/offd layout behind HYPRE_IJMatrixAssemble (solvers.c:362) and the halo
+ * exchange / MPI_Allreduce inside HYPRE's matvec and inner products.  Unlike solvers.c:263-265
+ * the whole matrix is never replicated: each rank hands in its own rows only. */
+typedef struct mk_comm mk_comm;
+typedef struct mk_dist_matrix mk_dist_matrix;
+/* rank 0 draws 256 opaque bytes (two ncclUniqueId) and passes them to every rank by any
+ * means (MPI_Bcast in solvers.c, torch.distributed in bench.py); then all ranks call create */
+int mk_comm_get_unique_id(void *id256);
+int mk_comm_create(const void *id256, int nranks, int rank, mk_comm **comm);   /* MPI_Init + MPI_Comm_rank/size (solvers.c:68-70) */
+/* several logical ranks inside ONE process on one GPU (tests): exchange = device copies */
+int mk_comm_create_local(int nranks, mk_comm **comms);
+int mk_comm_destroy(mk_comm *comm);
+/* A holds rows [row_start[rank], row_start[rank+1]) of the global operator with GLOBAL column
+ * ids (ncols = n_global) and is consumed.  Collective. comm may be NULL for a single rank. */
+int mk_dist_matrix_create(mk_matrix *A, int64_t n_global, const int64_t *row_start, mk_comm *comm, mk_dist_matrix **out);
+int mk_dist_matrix_destroy(mk_dist_matrix *A);
+int mk_dist_matrix_get_info(const mk_dist_matrix *A, int64_t *n_local, int64_t *n_ghost, int64_t *n_offd_rows,
+                            int64_t *nnz_diag, int64_t *nnz_offd, int *n_neighbors);
+/* vector of n_local owned entries with room for the ghost entries behind them */
+int mk_dist_vector_create(const mk_dist_matrix *A, mk_vector **v);
+/* nranks_here = 1 over RCCL, = world size for a local world (arrays in rank order) */
+int mk_dist_spmv(int nranks_here, mk_dist_matrix **A, mk_vector **x, mk_vector **y);
+/* HYPRE_ParCSRPCGSetup + HYPRE_ParCSRPCGSolve (solvers.c:747-754) on the distributed operator;
+ * settings and results through the mk_pcg_set_* / mk_pcg_get_* calls above */
+int mk_dist_pcg_solve(int nranks_here, mk_pcg **solvers, mk_dist_matrix **A, mk_vector **b, mk_vector **x);
+
 /* ---- row-block partition: solvers.c:214-231,270-281 with defects Q1-Q4 repaired ----------- */
 /* host-only; rowptr64 has nrows+1 entries; row_start gets nparts+1 entries */
 int mk_partition_rows(int64_t nrows, const int64_t *rowptr64, int nparts, int64_t *row_start);

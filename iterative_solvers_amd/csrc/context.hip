@@ -114,6 +114,7 @@ int mk_vector_create(int64_t n, mk_vector **v) {
   if (!v || n < 0) return fail(MK_ERR_INVALID, "mk_vector_create: bad arguments");
   mk_vector *p = new mk_vector();
   p->n = n;
+  p->cap = n;
   int rc = dev_alloc(&p->d, (size_t)n);
   if (rc != MK_OK) {
     delete p;

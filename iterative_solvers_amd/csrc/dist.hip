@@ -1,0 +1,756 @@
+// dist.hip -- row-block distributed SpMV and CG: one rank per GPU, RCCL over xGMI.
+//
+// Reference counterpart: solvers.c:214-281 partitions the row-sorted COO into contiguous
+// nnz-balanced row blocks, one per MPI rank, and HYPRE's ParCSR format then keeps, per rank,
+// a "diag" block (columns it owns), an "offd" block (columns owned by others, renumbered
+// into a compact ghost range) and a communication package; its matvec posts the halo
+// exchange, multiplies the diag block, waits, multiplies the offd block, and every inner
+// product ends in MPI_Allreduce of one double (all inside HYPRE, not in /root/reference).
+// Here:
+//   - the reference broadcasts the WHOLE COO to every rank first (solvers.c:263-265); this
+//     library never does: every rank builds or uploads only its own rows;
+//   - halo: pack kernel + grouped ncclSend/ncclRecv on a communication stream, received
+//     straight into the ghost tail of the vector, overlapped with the diag-block SpMV;
+//   - inner products: the fused kernels leave per-block partials, one small kernel folds
+//     them, ONE ncclAllReduce carries both dots of a step (2 and 3 doubles per iteration);
+//   - two communicators (point-to-point and collective) so that the halo of the next step
+//     may run beside an all-reduce without two kernels of one communicator in flight.
+// RCCL is resolved with dlopen at first use, so single-GPU users need no RCCL at all.
+//
+// For tests on one GPU the same code drives several logical ranks inside one process
+// ("local world"): the exchange becomes device-to-device copies and the all-reduce a small
+// kernel, everything else (partition, ghost maps, diag/offd split, solver) is identical.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+
+#include "krylov_kernels.h"
+
+struct mk_dist_matrix;
+
+namespace mk {
+
+// --------------------------------------------------------------------------- RCCL binding
+struct Rccl {
+  void *handle = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  const char *(*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+};
+
+static Rccl g_rccl;
+
+static int load_rccl() {
+  if (g_rccl.handle) return MK_OK;
+  const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  void *h = nullptr;
+  for (const char *nm : names) {
+    h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+    if (h) break;
+  }
+  if (!h) return fail(MK_ERR_COMM, "cannot dlopen librccl: %s", dlerror());
+#define MK_SYM(field, name)                                                         \
+  *(void **)(&g_rccl.field) = dlsym(h, name);                                       \
+  if (!g_rccl.field) return fail(MK_ERR_COMM, "librccl lacks symbol %s", name);
+  MK_SYM(GetUniqueId, "ncclGetUniqueId")
+  MK_SYM(CommInitRank, "ncclCommInitRank")
+  MK_SYM(CommDestroy, "ncclCommDestroy")
+  MK_SYM(GetErrorString, "ncclGetErrorString")
+  MK_SYM(AllReduce, "ncclAllReduce")
+  MK_SYM(AllGather, "ncclAllGather")
+  MK_SYM(Send, "ncclSend")
+  MK_SYM(Recv, "ncclRecv")
+  MK_SYM(GroupStart, "ncclGroupStart")
+  MK_SYM(GroupEnd, "ncclGroupEnd")
+#undef MK_SYM
+  g_rccl.handle = h;
+  return MK_OK;
+}
+
+#define MK_NCCL(call)                                                                                 \
+  do {                                                                                                \
+    ncclResult_t r_ = (call);                                                                         \
+    if (r_ != ncclSuccess)                                                                            \
+      return mk::fail(MK_ERR_COMM, "%s:%d: %s -> %s", __FILE__, __LINE__, #call, g_rccl.GetErrorString(r_)); \
+  } while (0)
+
+struct LocalWorld;
+
+}  // namespace mk
+
+struct mk_comm {
+  int nranks = 1, rank = 0;
+  bool local = false;
+  mk::LocalWorld *world = nullptr;
+  ncclComm_t coll = nullptr, p2p = nullptr;
+  hipStream_t comm_stream = nullptr;
+  hipEvent_t ev_ready = nullptr, ev_halo = nullptr;
+};
+
+struct mk_dist_matrix {
+  mk_comm *comm = nullptr;
+  int nranks = 1, rank = 0;
+  int64_t n_global = 0, row_begin = 0, row_end = 0, n_local = 0, n_ghost = 0;
+  std::vector<int64_t> row_start;
+  mk_matrix diag;              // n_local x n_local, local column ids
+  mk_matrix offd;              // n_offd_rows x n_ghost (compressed rows)
+  int *offd_rows = nullptr;    // local row of each offd row
+  int n_offd_rows = 0;
+  int offd_lanes = 1;
+  int *ghost_global = nullptr; // device, sorted global ids of the ghosts
+  std::vector<int> h_ghost;
+  std::vector<int> recv_cnt, recv_off, send_cnt, send_off;
+  int n_send = 0;
+  int *send_idx = nullptr;     // device: local rows to pack, grouped by destination
+  double *sendbuf = nullptr;
+  bool plan_ready = false;
+};
+
+namespace mk {
+
+struct LocalWorld {
+  int nranks = 0;
+  std::vector<mk_comm *> comms;
+  std::vector<mk_dist_matrix *> mats;   // registered by rank
+  double **d_ptrs = nullptr;            // device array of nranks pointers (all-reduce emulation)
+};
+
+// ------------------------------------------------------------------------------ kernels
+__global__ void flag_ghost_cols_kernel(int64_t nnz, const int *__restrict__ col, int rb, int re, uint32_t *__restrict__ flags) {
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += (int64_t)gridDim.x * blockDim.x) {
+    const int c = col[k];
+    if (c < rb || c >= re) flags[c] = 1u;
+  }
+}
+
+__global__ void compact_ghosts_kernel(int64_t n_global, const uint32_t *__restrict__ scanned, uint32_t total, int *__restrict__ ghost) {
+  for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n_global; c += (int64_t)gridDim.x * blockDim.x) {
+    const uint32_t here = scanned[c];
+    const uint32_t next = (c + 1 < n_global) ? scanned[c + 1] : total;
+    if (next != here) ghost[here] = (int)c;
+  }
+}
+
+__global__ void split_count_kernel(int64_t nrows, const int *__restrict__ rowptr, const int *__restrict__ col, int rb, int re,
+                                   uint32_t *__restrict__ cnt_d, uint32_t *__restrict__ cnt_o, uint32_t *__restrict__ has_o) {
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += (int64_t)gridDim.x * blockDim.x) {
+    uint32_t d = 0, o = 0;
+    for (int k = rowptr[r]; k < rowptr[r + 1]; k++) {
+      const int c = col[k];
+      if (c >= rb && c < re) d++; else o++;
+    }
+    cnt_d[r] = d;
+    cnt_o[r] = o;
+    has_o[r] = o ? 1u : 0u;
+  }
+}
+
+__global__ void split_fill_kernel(int64_t nrows, const int *__restrict__ rowptr, const int *__restrict__ col,
+                                  const double *__restrict__ val, int rb, int re, const uint32_t *__restrict__ ghost_pos,
+                                  const int *__restrict__ d_rowptr, int *__restrict__ d_col, double *__restrict__ d_val,
+                                  const uint32_t *__restrict__ o_off, const uint32_t *__restrict__ o_rowpos,
+                                  const uint32_t *__restrict__ has_o, int *__restrict__ o_rowptr, int *__restrict__ o_rows,
+                                  int *__restrict__ o_col, double *__restrict__ o_val) {
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += (int64_t)gridDim.x * blockDim.x) {
+    int dp = d_rowptr[r];
+    uint32_t op = o_off[r];
+    if (has_o[r]) {
+      o_rowptr[o_rowpos[r]] = (int)op;
+      o_rows[o_rowpos[r]] = (int)r;
+    }
+    for (int k = rowptr[r]; k < rowptr[r + 1]; k++) {
+      const int c = col[k];
+      if (c >= rb && c < re) {
+        d_col[dp] = c - rb;
+        d_val[dp++] = val[k];
+      } else {
+        o_col[op] = (int)ghost_pos[c];
+        o_val[op++] = val[k];
+      }
+    }
+  }
+}
+
+__global__ void set_int_kernel(int *p, int v) { *p = v; }
+__global__ void add_int_kernel(int *p, int64_t n, int delta) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] += delta;
+}
+
+__global__ void pack_kernel(int n, const int *__restrict__ idx, const double *__restrict__ v, double *__restrict__ out) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = v[idx[i]];
+}
+
+// y[rows[i]] += alpha * sum_k val[k] * xghost[col[k]]  over the offd block; with DOT the
+// per-block partial of sum_i (contribution_i * xlocal[rows[i]]) goes to slab component 0
+// (component 1 gets 0) so that <A p, p> can be completed after the diag pass.
+template <int G, bool DOT>
+__global__ __launch_bounds__(256) void offd_spmv_kernel(int nrows, const int *__restrict__ rowptr, const int *__restrict__ col,
+                                                        const double *__restrict__ val, const int *__restrict__ rows,
+                                                        const double *__restrict__ xghost, const double *__restrict__ xlocal,
+                                                        double *__restrict__ y, double alpha, double *__restrict__ slab,
+                                                        const int *__restrict__ done) {
+  if (done != nullptr && *done != 0) return;
+  constexpr int ROWS = 256 / G;
+  const int g = threadIdx.x % G, rl = threadIdx.x / G;
+  double acc = 0.0;
+  for (int base = blockIdx.x * ROWS; base < nrows; base += gridDim.x * ROWS) {
+    const int i = base + rl;
+    double sum = 0.0;
+    if (i < nrows)
+      for (int k = rowptr[i] + g; k < rowptr[i + 1]; k += G) sum += val[k] * xghost[col[k]];
+    sum = group_sum<G>(sum);
+    if (g == 0 && i < nrows) {
+      const int r = rows[i];
+      const double add = alpha * sum;
+      y[r] += add;
+      if (DOT) acc += add * xlocal[r];
+    }
+  }
+  if (DOT) {
+    __shared__ double smem[256 / 64];
+    double v[1] = {acc};
+    block_sum<1, 256>(v, smem);
+    if (threadIdx.x == 0) {
+      slab[0 * kSlabStride + blockIdx.x] = v[0];
+      slab[1 * kSlabStride + blockIdx.x] = 0.0;
+    }
+  }
+}
+
+__global__ void local_allreduce_kernel(double **bufs, int nranks, int count) {
+  const int k = threadIdx.x;
+  if (k >= count) return;
+  double s = 0.0;
+  for (int r = 0; r < nranks; r++) s += bufs[r][k];
+  for (int r = 0; r < nranks; r++) bufs[r][k] = s;
+}
+
+static int grid1(int64_t n, int cap = 4096) { return (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, cap)); }
+
+static void release_dist(mk_dist_matrix *D) {
+  auto freem = [](mk_matrix &M) {
+    dev_free(M.rowptr); dev_free(M.col); dev_free(M.val); dev_free(M.dinv); dev_free(M.chunk_row); dev_free(M.long_rows);
+    M = mk_matrix();
+  };
+  freem(D->diag);
+  freem(D->offd);
+  dev_free(D->offd_rows); dev_free(D->ghost_global); dev_free(D->send_idx); dev_free(D->sendbuf);
+}
+
+// split a local row block with GLOBAL column ids into diag + offd and list its ghosts
+static int split_block(mk_matrix *A, mk_dist_matrix *D) {
+  Context &c = ctx();
+  const int64_t nl = D->n_local, ng = D->n_global;
+  const int rb = (int)D->row_begin, re = (int)D->row_end;
+  uint32_t *flags = nullptr, *cnt_d = nullptr, *cnt_o = nullptr, *has_o = nullptr, *d_tot = nullptr;
+  MK_TRY(dev_alloc(&flags, (size_t)ng));
+  MK_TRY(dev_alloc(&cnt_d, (size_t)nl));
+  MK_TRY(dev_alloc(&cnt_o, (size_t)nl));
+  MK_TRY(dev_alloc(&has_o, (size_t)nl));
+  MK_TRY(dev_alloc(&d_tot, 4));
+  MK_HIP(hipMemsetAsync(flags, 0, sizeof(uint32_t) * (size_t)ng, c.stream));
+  if (A->nnz) hipLaunchKernelGGL(flag_ghost_cols_kernel, dim3(grid1(A->nnz, 8192)), dim3(256), 0, c.stream, A->nnz, A->col, rb, re, flags);
+  MK_TRY(exclusive_scan_u32(flags, flags, (size_t)ng, d_tot + 0));
+  if (nl) hipLaunchKernelGGL(split_count_kernel, dim3(grid1(nl)), dim3(256), 0, c.stream, nl, A->rowptr, A->col, rb, re, cnt_d, cnt_o, has_o);
+  uint32_t h_tot[4] = {0, 0, 0, 0};
+  MK_TRY(dev_alloc(&D->diag.rowptr, (size_t)nl + 1));
+  MK_TRY(exclusive_scan_u32(cnt_d, reinterpret_cast<uint32_t *>(D->diag.rowptr), (size_t)nl, d_tot + 1));
+  MK_TRY(exclusive_scan_u32(cnt_o, cnt_o, (size_t)nl, d_tot + 2));        // cnt_o -> offset of the row's offd entries
+  uint32_t *o_rowpos = cnt_d;                                             // reuse: position among offd rows
+  MK_TRY(exclusive_scan_u32(has_o, o_rowpos, (size_t)nl, d_tot + 3));
+  MK_HIP(hipMemcpyAsync(h_tot, d_tot, sizeof(h_tot), hipMemcpyDeviceToHost, c.stream));
+  MK_HIP(hipStreamSynchronize(c.stream));
+  D->n_ghost = h_tot[0];
+  D->n_offd_rows = (int)h_tot[3];
+  D->diag.nrows = nl; D->diag.ncols = nl; D->diag.nnz = h_tot[1];
+  D->offd.nrows = D->n_offd_rows; D->offd.ncols = D->n_ghost; D->offd.nnz = h_tot[2];
+  if ((int64_t)h_tot[1] + h_tot[2] != A->nnz) return fail(MK_ERR_INVALID, "dist split: entry counts do not add up");
+  MK_TRY(dev_alloc(&D->diag.col, (size_t)D->diag.nnz));
+  MK_TRY(dev_alloc(&D->diag.val, (size_t)D->diag.nnz));
+  MK_TRY(dev_alloc(&D->offd.rowptr, (size_t)D->n_offd_rows + 1));
+  MK_TRY(dev_alloc(&D->offd.col, (size_t)D->offd.nnz));
+  MK_TRY(dev_alloc(&D->offd.val, (size_t)D->offd.nnz));
+  MK_TRY(dev_alloc(&D->offd_rows, (size_t)D->n_offd_rows));
+  MK_TRY(dev_alloc(&D->ghost_global, (size_t)D->n_ghost));
+  hipLaunchKernelGGL(set_int_kernel, dim3(1), dim3(1), 0, c.stream, D->diag.rowptr + nl, (int)D->diag.nnz);
+  hipLaunchKernelGGL(set_int_kernel, dim3(1), dim3(1), 0, c.stream, D->offd.rowptr + D->n_offd_rows, (int)D->offd.nnz);
+  if (D->n_ghost) hipLaunchKernelGGL(compact_ghosts_kernel, dim3(grid1(ng, 8192)), dim3(256), 0, c.stream, ng, flags, h_tot[0], D->ghost_global);
+  if (nl) hipLaunchKernelGGL(split_fill_kernel, dim3(grid1(nl)), dim3(256), 0, c.stream, nl, A->rowptr, A->col, A->val, rb, re, flags,
+                             D->diag.rowptr, D->diag.col, D->diag.val, cnt_o, o_rowpos, has_o, D->offd.rowptr, D->offd_rows,
+                             D->offd.col, D->offd.val);
+  D->h_ghost.resize((size_t)D->n_ghost);
+  if (D->n_ghost) MK_HIP(hipMemcpyAsync(D->h_ghost.data(), D->ghost_global, sizeof(int) * D->n_ghost, hipMemcpyDeviceToHost, c.stream));
+  MK_HIP(hipStreamSynchronize(c.stream));
+  MK_HIP(hipGetLastError());
+  dev_free(flags); dev_free(cnt_d); dev_free(cnt_o); dev_free(has_o); dev_free(d_tot);
+  // receive plan: ghosts are sorted by global id, owners are contiguous row blocks
+  D->recv_cnt.assign(D->nranks, 0);
+  D->recv_off.assign(D->nranks + 1, 0);
+  for (int q = 0; q < D->nranks; q++) {
+    auto lo = std::lower_bound(D->h_ghost.begin(), D->h_ghost.end(), (int)D->row_start[q]);
+    auto hi = std::lower_bound(D->h_ghost.begin(), D->h_ghost.end(), (int)std::min<int64_t>(D->row_start[q + 1], 0x7fffffff));
+    D->recv_cnt[q] = (int)(hi - lo);
+    D->recv_off[q + 1] = D->recv_off[q] + D->recv_cnt[q];
+  }
+  if (D->recv_cnt[D->rank] != 0) return fail(MK_ERR_INVALID, "dist split: own rows listed as ghosts");
+  const double mean_o = D->n_offd_rows ? (double)D->offd.nnz / D->n_offd_rows : 0.0;
+  int g = 1;
+  while (g < 64 && g < mean_o) g *= 2;
+  D->offd_lanes = g;
+  return MK_OK;
+}
+
+static int finish_send_plan(mk_dist_matrix *D) {
+  D->send_off.assign(D->nranks + 1, 0);
+  for (int q = 0; q < D->nranks; q++) D->send_off[q + 1] = D->send_off[q] + D->send_cnt[q];
+  D->n_send = D->send_off[D->nranks];
+  MK_TRY(dev_alloc(&D->send_idx, (size_t)D->n_send));
+  MK_TRY(dev_alloc(&D->sendbuf, (size_t)D->n_send));
+  return MK_OK;
+}
+
+// build the send side once every rank knows what it needs (collective)
+static int build_plan_rccl(mk_dist_matrix *D) {
+  Context &c = ctx();
+  mk_comm *cm = D->comm;
+  const int P = D->nranks;
+  int *d_cnt = nullptr, *d_all = nullptr;
+  MK_TRY(dev_alloc(&d_cnt, (size_t)P));
+  MK_TRY(dev_alloc(&d_all, (size_t)P * P));
+  MK_HIP(hipMemcpyAsync(d_cnt, D->recv_cnt.data(), sizeof(int) * P, hipMemcpyHostToDevice, c.stream));
+  MK_NCCL(g_rccl.AllGather(d_cnt, d_all, (size_t)P, ncclInt32, cm->coll, c.stream));
+  std::vector<int> all((size_t)P * P);
+  MK_HIP(hipMemcpyAsync(all.data(), d_all, sizeof(int) * P * P, hipMemcpyDeviceToHost, c.stream));
+  MK_HIP(hipStreamSynchronize(c.stream));
+  dev_free(d_cnt); dev_free(d_all);
+  D->send_cnt.assign(P, 0);
+  for (int q = 0; q < P; q++) D->send_cnt[q] = all[(size_t)q * P + D->rank];   // what q needs from me
+  MK_TRY(finish_send_plan(D));
+  MK_NCCL(g_rccl.GroupStart());
+  for (int q = 0; q < P; q++) {
+    if (D->recv_cnt[q]) MK_NCCL(g_rccl.Send(D->ghost_global + D->recv_off[q], (size_t)D->recv_cnt[q], ncclInt32, q, cm->p2p, c.stream));
+    if (D->send_cnt[q]) MK_NCCL(g_rccl.Recv(D->send_idx + D->send_off[q], (size_t)D->send_cnt[q], ncclInt32, q, cm->p2p, c.stream));
+  }
+  MK_NCCL(g_rccl.GroupEnd());
+  if (D->n_send) hipLaunchKernelGGL(add_int_kernel, dim3(grid1(D->n_send)), dim3(256), 0, c.stream, D->send_idx, (int64_t)D->n_send, -(int)D->row_begin);
+  MK_HIP(hipStreamSynchronize(c.stream));
+  D->plan_ready = true;
+  return MK_OK;
+}
+
+static int build_plan_local(LocalWorld *W) {
+  Context &c = ctx();
+  const int P = W->nranks;
+  for (int r = 0; r < P; r++) {
+    mk_dist_matrix *D = W->mats[r];
+    D->send_cnt.assign(P, 0);
+    for (int q = 0; q < P; q++) D->send_cnt[q] = W->mats[q]->recv_cnt[r];
+    MK_TRY(finish_send_plan(D));
+    for (int q = 0; q < P; q++)
+      if (D->send_cnt[q])
+        MK_HIP(hipMemcpyAsync(D->send_idx + D->send_off[q], W->mats[q]->ghost_global + W->mats[q]->recv_off[r],
+                              sizeof(int) * D->send_cnt[q], hipMemcpyDeviceToDevice, c.stream));
+    if (D->n_send) hipLaunchKernelGGL(add_int_kernel, dim3(grid1(D->n_send)), dim3(256), 0, c.stream, D->send_idx, (int64_t)D->n_send, -(int)D->row_begin);
+    D->plan_ready = true;
+  }
+  MK_HIP(hipStreamSynchronize(c.stream));
+  return MK_OK;
+}
+
+// ------------------------------------------------------------------- communication phases
+// v[r] has n_local owned entries followed by n_ghost ghost entries
+static int halo_exchange(int R, mk_dist_matrix **A, double **v, bool overlap) {
+  Context &c = ctx();
+  if (A[0]->nranks == 1) return MK_OK;
+  if (A[0]->comm->local) {
+    for (int r = 0; r < R; r++)
+      if (A[r]->n_send) hipLaunchKernelGGL(pack_kernel, dim3(grid1(A[r]->n_send, 1024)), dim3(256), 0, c.stream, A[r]->n_send, A[r]->send_idx, v[r], A[r]->sendbuf);
+    for (int r = 0; r < R; r++)
+      for (int q = 0; q < R; q++)
+        if (A[r]->recv_cnt[q])
+          MK_HIP(hipMemcpyAsync(v[r] + A[r]->n_local + A[r]->recv_off[q], A[q]->sendbuf + A[q]->send_off[r],
+                                sizeof(double) * A[r]->recv_cnt[q], hipMemcpyDeviceToDevice, c.stream));
+    return MK_OK;
+  }
+  mk_dist_matrix *D = A[0];
+  mk_comm *cm = D->comm;
+  hipStream_t s = overlap ? cm->comm_stream : c.stream;
+  if (overlap) {
+    MK_HIP(hipEventRecord(cm->ev_ready, c.stream));
+    MK_HIP(hipStreamWaitEvent(s, cm->ev_ready, 0));
+  }
+  if (D->n_send) hipLaunchKernelGGL(pack_kernel, dim3(grid1(D->n_send, 1024)), dim3(256), 0, s, D->n_send, D->send_idx, v[0], D->sendbuf);
+  MK_NCCL(g_rccl.GroupStart());
+  for (int q = 0; q < D->nranks; q++) {
+    if (D->send_cnt[q]) MK_NCCL(g_rccl.Send(D->sendbuf + D->send_off[q], (size_t)D->send_cnt[q], ncclDouble, q, cm->p2p, s));
+    if (D->recv_cnt[q]) MK_NCCL(g_rccl.Recv(v[0] + D->n_local + D->recv_off[q], (size_t)D->recv_cnt[q], ncclDouble, q, cm->p2p, s));
+  }
+  MK_NCCL(g_rccl.GroupEnd());
+  if (overlap) MK_HIP(hipEventRecord(cm->ev_halo, s));
+  return MK_OK;
+}
+
+static int halo_wait(mk_dist_matrix *D, bool overlap) {
+  if (D->nranks == 1 || D->comm->local || !overlap) return MK_OK;
+  MK_HIP(hipStreamWaitEvent(ctx().stream, D->comm->ev_halo, 0));
+  return MK_OK;
+}
+
+static int all_reduce(int R, mk_dist_matrix **A, double **bufs, int count) {
+  Context &c = ctx();
+  if (A[0]->nranks == 1) return MK_OK;
+  if (A[0]->comm->local) {
+    LocalWorld *W = A[0]->comm->world;
+    MK_HIP(hipMemcpyAsync(W->d_ptrs, bufs, sizeof(double *) * R, hipMemcpyHostToDevice, c.stream));
+    hipLaunchKernelGGL(local_allreduce_kernel, dim3(1), dim3(64), 0, c.stream, W->d_ptrs, R, count);
+    // bufs is a host array owned by the caller and may be reused: the copy above must have left it
+    MK_HIP(hipStreamSynchronize(c.stream));
+    return MK_OK;
+  }
+  MK_NCCL(g_rccl.AllReduce(bufs[0], bufs[0], (size_t)count, ncclDouble, ncclSum, A[0]->comm->coll, c.stream));
+  return MK_OK;
+}
+
+template <bool DOT>
+static int launch_offd(const mk_dist_matrix *D, const double *xext, double *y, double alpha, double *slab, const int *done, int *nblocks) {
+  Context &c = ctx();
+  const int G = D->offd_lanes;
+  const int rows_per_block = 256 / G;
+  int blocks = std::max(1, std::min((D->n_offd_rows + rows_per_block - 1) / rows_per_block, 1024));
+  if (nblocks) *nblocks = blocks;
+  if (D->n_offd_rows == 0 && !DOT) return MK_OK;
+#define MK_OFFD(GG) case GG: hipLaunchKernelGGL((offd_spmv_kernel<GG, DOT>), dim3(blocks), dim3(256), 0, c.stream, D->n_offd_rows, \
+    D->offd.rowptr, D->offd.col, D->offd.val, D->offd_rows, xext + D->n_local, xext, y, alpha, slab, done); break;
+  switch (G) { MK_OFFD(1) MK_OFFD(2) MK_OFFD(4) MK_OFFD(8) MK_OFFD(16) MK_OFFD(32) MK_OFFD(64) default: return fail(MK_ERR_INVALID, "offd lanes"); }
+#undef MK_OFFD
+  MK_HIP(hipGetLastError());
+  return MK_OK;
+}
+
+struct DistWork {
+  double *r = nullptr, *p = nullptr, *s = nullptr, *slab1 = nullptr, *slab2 = nullptr, *buf = nullptr, *norms = nullptr;
+  PcgState *state = nullptr;
+  void release() {
+    dev_free(r); dev_free(p); dev_free(s); dev_free(slab1); dev_free(slab2); dev_free(buf); dev_free(state); dev_free(norms);
+  }
+};
+
+}  // namespace mk
+
+using namespace mk;
+
+extern "C" {
+
+// ------------------------------------------------------------------------ communicators
+int mk_comm_get_unique_id(void *id256) {
+  if (!id256) return fail(MK_ERR_INVALID, "mk_comm_get_unique_id: null buffer");
+  MK_TRY(load_rccl());
+  ncclUniqueId a, b;
+  MK_NCCL(g_rccl.GetUniqueId(&a));
+  MK_NCCL(g_rccl.GetUniqueId(&b));
+  memcpy(id256, &a, 128);
+  memcpy((char *)id256 + 128, &b, 128);
+  return MK_OK;
+}
+
+int mk_comm_create(const void *id256, int nranks, int rank, mk_comm **comm) {
+  MK_REQUIRE_INIT();
+  if (!id256 || !comm || nranks < 1 || rank < 0 || rank >= nranks) return fail(MK_ERR_INVALID, "mk_comm_create: bad argument");
+  MK_TRY(load_rccl());
+  mk_comm *cm = new mk_comm();
+  cm->nranks = nranks; cm->rank = rank;
+  ncclUniqueId a, b;
+  memcpy(&a, id256, 128);
+  memcpy(&b, (const char *)id256 + 128, 128);
+  MK_NCCL(g_rccl.CommInitRank(&cm->coll, nranks, a, rank));
+  MK_NCCL(g_rccl.CommInitRank(&cm->p2p, nranks, b, rank));
+  MK_HIP(hipStreamCreateWithFlags(&cm->comm_stream, hipStreamNonBlocking));
+  MK_HIP(hipEventCreateWithFlags(&cm->ev_ready, hipEventDisableTiming));
+  MK_HIP(hipEventCreateWithFlags(&cm->ev_halo, hipEventDisableTiming));
+  *comm = cm;
+  return MK_OK;
+}
+
+int mk_comm_create_local(int nranks, mk_comm **comms) {
+  MK_REQUIRE_INIT();
+  if (!comms || nranks < 1 || nranks > 64) return fail(MK_ERR_INVALID, "mk_comm_create_local: bad argument");
+  LocalWorld *W = new LocalWorld();
+  W->nranks = nranks;
+  W->mats.assign(nranks, nullptr);
+  MK_TRY(dev_alloc(&W->d_ptrs, (size_t)nranks));
+  for (int r = 0; r < nranks; r++) {
+    mk_comm *cm = new mk_comm();
+    cm->nranks = nranks; cm->rank = r; cm->local = true; cm->world = W;
+    W->comms.push_back(cm);
+    comms[r] = cm;
+  }
+  return MK_OK;
+}
+
+int mk_comm_destroy(mk_comm *cm) {
+  if (!cm) return MK_OK;
+  if (ctx().ready) (void)hipDeviceSynchronize();
+  if (cm->local) {
+    LocalWorld *W = cm->world;
+    W->comms[cm->rank] = nullptr;
+    bool last = true;
+    for (mk_comm *o : W->comms) if (o) last = false;
+    if (last) { dev_free(W->d_ptrs); delete W; }
+  } else {
+    if (cm->coll) (void)g_rccl.CommDestroy(cm->coll);
+    if (cm->p2p) (void)g_rccl.CommDestroy(cm->p2p);
+    if (cm->ev_ready) (void)hipEventDestroy(cm->ev_ready);
+    if (cm->ev_halo) (void)hipEventDestroy(cm->ev_halo);
+    if (cm->comm_stream) (void)hipStreamDestroy(cm->comm_stream);
+  }
+  delete cm;
+  return MK_OK;
+}
+
+// ---------------------------------------------------------------------- distributed matrix
+int mk_dist_matrix_create(mk_matrix *A, int64_t n_global, const int64_t *row_start, mk_comm *comm, mk_dist_matrix **out) {
+  MK_REQUIRE_INIT();
+  if (!A || !row_start || !out) return fail(MK_ERR_INVALID, "mk_dist_matrix_create: null argument");
+  const int P = comm ? comm->nranks : 1, me = comm ? comm->rank : 0;
+  if (P > 1 && !comm->local && !comm->coll) return fail(MK_ERR_INVALID, "mk_dist_matrix_create: communicator not initialised");
+  if (n_global > 0x7fffffffLL) return fail(MK_ERR_UNSUPPORTED, "mk_dist_matrix_create: more than 2^31-1 global columns");
+  if (row_start[0] != 0 || row_start[P] != n_global) return fail(MK_ERR_INVALID, "mk_dist_matrix_create: row_start must run from 0 to n_global");
+  for (int q = 0; q < P; q++)
+    if (row_start[q + 1] < row_start[q]) return fail(MK_ERR_INVALID, "mk_dist_matrix_create: row_start decreases");
+  if (A->nrows != row_start[me + 1] - row_start[me] || A->ncols != n_global)
+    return fail(MK_ERR_INVALID, "mk_dist_matrix_create: block is %lld x %lld, expected %lld x %lld", (long long)A->nrows,
+                (long long)A->ncols, (long long)(row_start[me + 1] - row_start[me]), (long long)n_global);
+  mk_dist_matrix *D = new mk_dist_matrix();
+  D->comm = comm; D->nranks = P; D->rank = me;
+  D->n_global = n_global;
+  D->row_start.assign(row_start, row_start + P + 1);
+  D->row_begin = row_start[me]; D->row_end = row_start[me + 1];
+  D->n_local = D->row_end - D->row_begin;
+  int rc = split_block(A, D);
+  if (rc == MK_OK) {
+    if (P == 1) {
+      D->send_cnt.assign(1, 0);
+      rc = finish_send_plan(D);
+      D->plan_ready = true;
+    } else if (comm->local) {
+      LocalWorld *W = comm->world;
+      W->mats[me] = D;
+      bool all = true;
+      for (mk_dist_matrix *m : W->mats) if (!m) all = false;
+      if (all) rc = build_plan_local(W);
+    } else {
+      rc = build_plan_rccl(D);
+    }
+  }
+  if (rc != MK_OK) { release_dist(D); delete D; return rc; }
+  mk_matrix_destroy(A);   // the block with global column ids is consumed
+  *out = D;
+  return MK_OK;
+}
+
+int mk_dist_matrix_destroy(mk_dist_matrix *D) {
+  if (!D) return MK_OK;
+  if (ctx().ready) (void)hipDeviceSynchronize();
+  if (D->comm && D->comm->local && D->comm->world) D->comm->world->mats[D->rank] = nullptr;
+  release_dist(D);
+  delete D;
+  return MK_OK;
+}
+
+int mk_dist_matrix_get_info(const mk_dist_matrix *D, int64_t *n_local, int64_t *n_ghost, int64_t *n_offd_rows, int64_t *nnz_diag,
+                            int64_t *nnz_offd, int *n_neighbors) {
+  if (!D) return fail(MK_ERR_INVALID, "mk_dist_matrix_get_info: null matrix");
+  if (n_local) *n_local = D->n_local;
+  if (n_ghost) *n_ghost = D->n_ghost;
+  if (n_offd_rows) *n_offd_rows = D->n_offd_rows;
+  if (nnz_diag) *nnz_diag = D->diag.nnz;
+  if (nnz_offd) *nnz_offd = D->offd.nnz;
+  if (n_neighbors) {
+    int k = 0;
+    for (int q = 0; q < D->nranks; q++) if (D->recv_cnt[q] || (D->plan_ready && D->send_cnt[q])) k++;
+    *n_neighbors = k;
+  }
+  return MK_OK;
+}
+
+int mk_dist_vector_create(const mk_dist_matrix *D, mk_vector **v) {
+  MK_REQUIRE_INIT();
+  if (!D || !v) return fail(MK_ERR_INVALID, "mk_dist_vector_create: null argument");
+  mk_vector *p = new mk_vector();
+  p->n = D->n_local;
+  p->cap = D->n_local + D->n_ghost;
+  int rc = dev_alloc(&p->d, (size_t)p->cap);
+  if (rc != MK_OK) { delete p; return rc; }
+  *v = p;
+  return MK_OK;
+}
+
+static int check_ranks(const char *who, int R, mk_dist_matrix **A) {
+  if (R < 1 || !A) return fail(MK_ERR_INVALID, "%s: bad argument", who);
+  for (int r = 0; r < R; r++) {
+    if (!A[r]) return fail(MK_ERR_INVALID, "%s: null matrix", who);
+    if (!A[r]->plan_ready) return fail(MK_ERR_INVALID, "%s: exchange plan incomplete (create the matrices of all ranks first)", who);
+  }
+  const bool local = A[0]->comm && A[0]->comm->local;
+  if (local) {
+    if (R != A[0]->nranks) return fail(MK_ERR_INVALID, "%s: a local world of %d ranks must be driven with all of them", who, A[0]->nranks);
+    for (int r = 0; r < R; r++) if (A[r]->rank != r) return fail(MK_ERR_INVALID, "%s: matrices must be passed in rank order", who);
+  } else if (R != 1) {
+    return fail(MK_ERR_INVALID, "%s: one rank per process over RCCL", who);
+  }
+  return MK_OK;
+}
+
+// y = A x on every rank this process drives (collective over RCCL)
+int mk_dist_spmv(int R, mk_dist_matrix **A, mk_vector **x, mk_vector **y) {
+  MK_REQUIRE_INIT();
+  MK_TRY(check_ranks("mk_dist_spmv", R, A));
+  if (!x || !y) return fail(MK_ERR_INVALID, "mk_dist_spmv: null argument");
+  std::vector<double *> xv(R);
+  for (int r = 0; r < R; r++) {
+    if (!x[r] || !y[r] || x[r]->cap < A[r]->n_local + A[r]->n_ghost || y[r]->n < A[r]->n_local)
+      return fail(MK_ERR_INVALID, "mk_dist_spmv: vectors must come from mk_dist_vector_create of the same matrix");
+    xv[r] = x[r]->d;
+  }
+  MK_TRY(halo_exchange(R, A, xv.data(), true));
+  for (int r = 0; r < R; r++) MK_TRY(launch_spmv(&A[r]->diag, 1.0, x[r]->d, 0.0, y[r]->d));
+  for (int r = 0; r < R; r++) {
+    MK_TRY(halo_wait(A[r], true));
+    MK_TRY(launch_offd<false>(A[r], x[r]->d, y[r]->d, 1.0, nullptr, nullptr, nullptr));
+  }
+  return MK_OK;
+}
+
+// HYPRE_ParCSRPCGSetup + Solve over the row blocks (solvers.c:747-754 with num_procs > 1)
+int mk_dist_pcg_solve(int R, mk_pcg **solvers, mk_dist_matrix **A, mk_vector **b, mk_vector **x) {
+  MK_REQUIRE_INIT();
+  MK_TRY(check_ranks("mk_dist_pcg_solve", R, A));
+  if (!solvers || !b || !x) return fail(MK_ERR_INVALID, "mk_dist_pcg_solve: null argument");
+  Context &c = ctx();
+  mk_pcg *S0 = solvers[0];
+  for (int r = 0; r < R; r++) {
+    if (!solvers[r] || !b[r] || !x[r]) return fail(MK_ERR_INVALID, "mk_dist_pcg_solve: null argument");
+    if (b[r]->n != A[r]->n_local || x[r]->n != A[r]->n_local || x[r]->cap < A[r]->n_local + A[r]->n_ghost)
+      return fail(MK_ERR_INVALID, "mk_dist_pcg_solve: vectors must come from mk_dist_vector_create of the same matrix");
+    if (solvers[r]->max_iter != S0->max_iter || solvers[r]->tol != S0->tol || solvers[r]->precond != S0->precond)
+      return fail(MK_ERR_INVALID, "mk_dist_pcg_solve: ranks disagree on solver settings");
+  }
+  const bool rccl = A[0]->nranks > 1 && !A[0]->comm->local;
+  const bool want_norms = S0->logging > 0 || S0->print_level > 0;
+  std::vector<DistWork> W(R);
+  std::vector<double *> pv(R), xv(R), bufs(R);
+  std::vector<int> vb(R), nb1(R), nb2(R);
+  int rc = MK_OK;
+  auto cleanup = [&]() { (void)hipDeviceSynchronize(); for (auto &w : W) w.release(); };
+#define MK_D(expr) do { rc = (expr); if (rc != MK_OK) { cleanup(); return rc; } } while (0)
+#define MK_DH(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return fail(MK_ERR_HIP, "%s -> %s", #expr, hipGetErrorString(e_)); } } while (0)
+  for (int r = 0; r < R; r++) {
+    mk_dist_matrix *D = A[r];
+    const size_t nl = (size_t)D->n_local, ne = (size_t)(D->n_local + D->n_ghost);
+    MK_D(dev_alloc(&W[r].r, nl));
+    MK_D(dev_alloc(&W[r].p, ne));
+    MK_D(dev_alloc(&W[r].s, nl));
+    MK_D(dev_alloc(&W[r].slab1, (size_t)kMaxParts * kSlabStride));
+    MK_D(dev_alloc(&W[r].slab2, (size_t)kMaxParts * kSlabStride));
+    MK_D(dev_alloc(&W[r].buf, 8));
+    MK_D(dev_alloc(&W[r].state, 1));
+    if (want_norms) MK_D(dev_alloc(&W[r].norms, (size_t)S0->max_iter + 1));
+    MK_D(analyse_matrix(&D->diag));
+    if (S0->precond == MK_PRECOND_JACOBI) MK_D(ensure_dinv(&D->diag));   // the diagonal lives in the diag block
+    pv[r] = W[r].p; xv[r] = x[r]->d; bufs[r] = W[r].buf;
+    vb[r] = vec_blocks(D->n_local);
+    solvers[r]->iterations = 0; solvers[r]->rel_res_norm = 0.0; solvers[r]->converged = 0; solvers[r]->breakdown = 0;
+  }
+  PcgState *hst = static_cast<PcgState *>(c.pinned);
+  const int two_norm = S0->two_norm, rel_change = S0->rel_change;
+
+  // r = b - A x;  p = C r;  gamma = <r,p>;  bi_prod = <b,b>   (each dot all-reduced)
+  MK_D(halo_exchange(R, A, xv.data(), false));
+  for (int r = 0; r < R; r++) {
+    mk_dist_matrix *D = A[r];
+    const int64_t nl = D->n_local;
+    if (nl) hipLaunchKernelGGL(copy_kernel, dim3(vb[r]), dim3(256), 0, c.stream, W[r].r, b[r]->d, nl);
+    MK_D(launch_spmv(&D->diag, -1.0, x[r]->d, 1.0, W[r].r));
+    MK_D(launch_offd<false>(D, x[r]->d, W[r].r, -1.0, nullptr, nullptr, nullptr));
+    const double *dinv = (S0->precond == MK_PRECOND_JACOBI) ? D->diag.dinv : nullptr;
+    hipLaunchKernelGGL(pcg_init_vectors_kernel, dim3(vb[r]), dim3(kVecThreads), 0, c.stream, nl, b[r]->d, W[r].r, dinv, W[r].p, two_norm, W[r].slab2);
+    hipLaunchKernelGGL((finalize_slab_kernel<3>), dim3(1), dim3(kVecThreads), 0, c.stream, W[r].slab2, vb[r], W[r].buf);
+  }
+  MK_D(all_reduce(R, A, bufs.data(), 3));
+  for (int r = 0; r < R; r++)
+    hipLaunchKernelGGL(pcg_init_scalars_kernel, dim3(1), dim3(kVecThreads), 0, c.stream, W[r].buf, 1, 1, S0->tol, two_norm, W[r].state, W[r].norms);
+  MK_DH(hipMemcpyAsync(&hst[0], W[0].state, sizeof(PcgState), hipMemcpyDeviceToHost, c.stream));
+  MK_DH(hipStreamSynchronize(c.stream));
+  const bool zero_rhs = !(hst[0].bi_prod > 0.0);
+  if (zero_rhs) {
+    for (int r = 0; r < R; r++)
+      if (A[r]->n_local) hipLaunchKernelGGL(copy_kernel, dim3(vb[r]), dim3(256), 0, c.stream, x[r]->d, b[r]->d, A[r]->n_local);
+  }
+
+  bool stop = zero_rhs;
+  for (int it = 0; it < S0->max_iter && !stop; it++) {
+    MK_D(halo_exchange(R, A, pv.data(), rccl));                                  // on the communication stream over RCCL
+    for (int r = 0; r < R; r++)                                                   // K1a: diag block, overlaps the halo
+      MK_D(launch_spmv_dot(&A[r]->diag, W[r].p, W[r].s, W[r].slab1, &W[r].state->done, &nb1[r]));
+    for (int r = 0; r < R; r++) {                                                 // K1b: offd block once the ghosts are in
+      MK_D(halo_wait(A[r], rccl));
+      MK_D(launch_offd<true>(A[r], W[r].p, W[r].s, 1.0, W[r].slab1 + nb1[r], &W[r].state->done, &nb2[r]));
+      hipLaunchKernelGGL((finalize_slab_kernel<2>), dim3(1), dim3(kVecThreads), 0, c.stream, W[r].slab1, nb1[r] + nb2[r], W[r].buf);
+    }
+    MK_D(all_reduce(R, A, bufs.data(), 2));                                       // <s,p>, <p,p>
+    for (int r = 0; r < R; r++) {
+      const int64_t nl = A[r]->n_local;
+      double *buf3 = W[r].buf + 4;
+      if (S0->precond == MK_PRECOND_JACOBI)
+        hipLaunchKernelGGL((pcg_update_xr_kernel<true>), dim3(vb[r]), dim3(kVecThreads), 0, c.stream, nl, W[r].p, W[r].s, A[r]->diag.dinv, x[r]->d, W[r].r, W[r].buf, 1, 1, W[r].slab2, W[r].state);
+      else
+        hipLaunchKernelGGL((pcg_update_xr_kernel<false>), dim3(vb[r]), dim3(kVecThreads), 0, c.stream, nl, W[r].p, W[r].s, (const double *)nullptr, x[r]->d, W[r].r, W[r].buf, 1, 1, W[r].slab2, W[r].state);
+      hipLaunchKernelGGL((finalize_slab_kernel<3>), dim3(1), dim3(kVecThreads), 0, c.stream, W[r].slab2, vb[r], buf3);
+      bufs[r] = buf3;
+    }
+    MK_D(all_reduce(R, A, bufs.data(), 3));                                       // <r,z>, <r,r>, <x,x>
+    for (int r = 0; r < R; r++) {
+      const int64_t nl = A[r]->n_local;
+      if (S0->precond == MK_PRECOND_JACOBI)
+        hipLaunchKernelGGL((pcg_update_p_kernel<true>), dim3(vb[r]), dim3(kVecThreads), 0, c.stream, nl, W[r].r, A[r]->diag.dinv, W[r].p, W[r].buf + 4, 1, 1, two_norm, rel_change, W[r].state, W[r].norms);
+      else
+        hipLaunchKernelGGL((pcg_update_p_kernel<false>), dim3(vb[r]), dim3(kVecThreads), 0, c.stream, nl, W[r].r, (const double *)nullptr, W[r].p, W[r].buf + 4, 1, 1, two_norm, rel_change, W[r].state, W[r].norms);
+      bufs[r] = W[r].buf;
+    }
+    if ((it + 1) % S0->check_every == 0) {
+      MK_DH(hipMemcpyAsync(&hst[0], W[0].state, sizeof(PcgState), hipMemcpyDeviceToHost, c.stream));
+      MK_DH(hipStreamSynchronize(c.stream));
+      if (hst[0].done != 0) stop = true;   // the same on every rank: it derives from all-reduced values only
+    }
+  }
+  MK_DH(hipGetLastError());
+  MK_DH(hipMemcpyAsync(&hst[0], W[0].state, sizeof(PcgState), hipMemcpyDeviceToHost, c.stream));
+  MK_DH(hipDeviceSynchronize());
+  for (int r = 0; r < R; r++) {
+    solvers[r]->iterations = hst[0].iter;
+    solvers[r]->converged = hst[0].converged;
+    solvers[r]->breakdown = hst[0].breakdown;
+    solvers[r]->rel_res_norm = zero_rhs ? 0.0 : sqrt(hst[0].i_prod / hst[0].bi_prod);
+    // hand the residual history to the solver object so mk_pcg_get_residual_history works
+    if (want_norms) {
+      dev_free(solvers[r]->norms);
+      solvers[r]->norms = W[r].norms;
+      solvers[r]->norms_cap = S0->max_iter + 1;
+      W[r].norms = nullptr;
+    }
+  }
+  cleanup();
+#undef MK_D
+#undef MK_DH
+  return MK_OK;
+}
+
+}  // extern "C"

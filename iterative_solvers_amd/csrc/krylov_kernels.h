@@ -1,0 +1,218 @@
+// krylov_kernels.h -- device kernels of the fused CG iteration, shared by the single-GPU
+// solver (krylov.hip) and the row-block distributed solver (dist.hip).
+#pragma once
+#include <cfloat>
+#include <cmath>
+
+#include "mk_internal.h"
+
+namespace mk {
+
+constexpr int kVecThreads = 256;
+
+struct PcgState {
+  double gamma, gamma_old, alpha, pp, i_prod, bi_prod, eps, sdotp;
+  long long iter;
+  int done;        // 0 running, 1 converged, 2 breakdown
+  int converged;
+  int breakdown;   // 1 zero <s,p>, 2 subnormal alpha, 3 subnormal gamma
+  int pad;
+};
+
+// p = z = C r; partials of <b,b> (or <Cb,b>), <r,z>, <r,r>
+static __global__ __launch_bounds__(kVecThreads) void pcg_init_vectors_kernel(int64_t n, const double *__restrict__ b,
+                                                                       const double *__restrict__ r,
+                                                                       const double *__restrict__ dinv,
+                                                                       double *__restrict__ p, int two_norm,
+                                                                       double *__restrict__ slab) {
+  double v[3] = {0.0, 0.0, 0.0};
+  for (int64_t i = (int64_t)blockIdx.x * kVecThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kVecThreads) {
+    const double bi = b[i], ri = r[i];
+    const double di = dinv ? dinv[i] : 1.0;
+    const double zi = dinv ? ri * di : ri;
+    p[i] = zi;
+    v[0] += two_norm ? bi * bi : (bi * di) * bi;
+    v[1] += ri * zi;
+    v[2] += ri * ri;
+  }
+  __shared__ double smem[3 * (kVecThreads / 64)];
+  block_sum<3, kVecThreads>(v, smem);
+  if (threadIdx.x == 0)
+    for (int k = 0; k < 3; k++) slab[k * kSlabStride + blockIdx.x] = v[k];
+}
+
+static __global__ __launch_bounds__(kVecThreads) void pcg_init_scalars_kernel(const double *slab, int nblocks, int stride_in, double tol,
+                                                                       int two_norm, PcgState *st, double *norms) {
+  __shared__ double smem[3 * (kVecThreads / 64)];
+  double v[3];
+  reduce_slab<3, kVecThreads>(slab, nblocks, stride_in, v, smem);
+  if (threadIdx.x == 0) {
+    PcgState s;
+    memset(&s, 0, sizeof(s));
+    s.bi_prod = v[0];
+    s.gamma = v[1];
+    s.i_prod = two_norm ? v[2] : v[1];
+    s.eps = tol * tol;
+    s.done = (v[0] > 0.0) ? 0 : 1;  // zero right-hand side: x = b, nothing to iterate
+    *st = s;
+    if (norms) norms[0] = (v[0] > 0.0) ? sqrt(s.i_prod / v[0]) : 0.0;
+  }
+}
+
+// K2
+template <bool PRECOND>
+__global__ __launch_bounds__(kVecThreads) void pcg_update_xr_kernel(int64_t n, const double *__restrict__ p,
+                                                                    const double *__restrict__ s, const double *__restrict__ dinv,
+                                                                    double *__restrict__ x, double *__restrict__ r,
+                                                                    const double *__restrict__ slab_in, int nblocks_in, int stride_in,
+                                                                    double *__restrict__ slab_out, PcgState *st) {
+  if (st->done != 0) return;
+  __shared__ double smem[3 * (kVecThreads / 64)];
+  double d[2];
+  reduce_slab<2, kVecThreads>(slab_in, nblocks_in, stride_in, d, smem);
+  const double sdotp = d[0], pp = d[1];
+  const double gamma = st->gamma;
+  const bool leader = (blockIdx.x == 0 && threadIdx.x == 0);
+  if (sdotp == 0.0) {
+    if (leader) { st->iter += 1; st->breakdown = 1; st->done = 2; }
+    return;
+  }
+  const double alpha = gamma / sdotp;
+  if (!(alpha > DBL_MIN)) {
+    if (leader) { st->iter += 1; st->breakdown = 2; st->done = 2; }
+    return;
+  }
+  double v[3] = {0.0, 0.0, 0.0};
+  const int64_t n2 = n >> 1;
+  const double2 *p2 = reinterpret_cast<const double2 *>(p);
+  const double2 *s2 = reinterpret_cast<const double2 *>(s);
+  const double2 *d2 = reinterpret_cast<const double2 *>(dinv);
+  double2 *x2 = reinterpret_cast<double2 *>(x);
+  double2 *r2 = reinterpret_cast<double2 *>(r);
+  for (int64_t i = (int64_t)blockIdx.x * kVecThreads + threadIdx.x; i < n2; i += (int64_t)gridDim.x * kVecThreads) {
+    const double2 pv = p2[i], sv = s2[i];
+    double2 xv = x2[i], rv = r2[i];
+    xv.x += alpha * pv.x; xv.y += alpha * pv.y;
+    rv.x -= alpha * sv.x; rv.y -= alpha * sv.y;
+    x2[i] = xv;
+    r2[i] = rv;
+    double zx = rv.x, zy = rv.y;
+    if (PRECOND) { const double2 dv = d2[i]; zx *= dv.x; zy *= dv.y; }
+    v[0] += rv.x * zx + rv.y * zy;
+    v[1] += rv.x * rv.x + rv.y * rv.y;
+    v[2] += xv.x * xv.x + xv.y * xv.y;
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const int64_t i = n - 1;
+    const double xi = x[i] + alpha * p[i], ri = r[i] - alpha * s[i];
+    x[i] = xi; r[i] = ri;
+    const double zi = PRECOND ? ri * dinv[i] : ri;
+    v[0] += ri * zi; v[1] += ri * ri; v[2] += xi * xi;
+  }
+  block_sum<3, kVecThreads>(v, smem);
+  if (threadIdx.x == 0)
+    for (int k = 0; k < 3; k++) slab_out[k * kSlabStride + blockIdx.x] = v[k];
+  if (leader) { st->alpha = alpha; st->gamma_old = gamma; st->pp = pp; st->sdotp = sdotp; st->iter += 1; }
+}
+
+// K3
+template <bool PRECOND>
+__global__ __launch_bounds__(kVecThreads) void pcg_update_p_kernel(int64_t n, const double *__restrict__ r,
+                                                                   const double *__restrict__ dinv, double *__restrict__ p,
+                                                                   const double *__restrict__ slab_in, int nblocks_in, int stride_in,
+                                                                   int two_norm, int rel_change, PcgState *st,
+                                                                   double *__restrict__ norms) {
+  if (st->done != 0) return;
+  __shared__ double smem[3 * (kVecThreads / 64)];
+  double d[3];
+  reduce_slab<3, kVecThreads>(slab_in, nblocks_in, stride_in, d, smem);
+  const double gamma_new = d[0];
+  const double i_prod = two_norm ? d[1] : d[0];
+  const double xx = d[2];
+  const double bi_prod = st->bi_prod, eps = st->eps, alpha = st->alpha, pp = st->pp, gamma_old = st->gamma_old;
+  const bool leader = (blockIdx.x == 0 && threadIdx.x == 0);
+  bool conv = (i_prod / bi_prod < eps);
+  if (conv && rel_change && i_prod > 0.0) {
+    const double ratio = alpha * alpha * pp / xx;
+    if (ratio >= eps) conv = false;
+  }
+  const bool tiny_gamma = (gamma_new < DBL_MIN) && (-gamma_new < DBL_MIN);
+  if (leader) {
+    st->gamma = gamma_new;
+    st->i_prod = i_prod;
+    if (norms) norms[st->iter] = sqrt(i_prod / bi_prod);
+    if (conv) { st->converged = 1; st->done = 1; }
+    else if (tiny_gamma) { st->breakdown = 3; st->done = 2; }
+  }
+  if (conv || tiny_gamma) return;
+  const double beta = gamma_new / gamma_old;
+  const int64_t n2 = n >> 1;
+  const double2 *r2 = reinterpret_cast<const double2 *>(r);
+  const double2 *d2 = reinterpret_cast<const double2 *>(dinv);
+  double2 *p2 = reinterpret_cast<double2 *>(p);
+  for (int64_t i = (int64_t)blockIdx.x * kVecThreads + threadIdx.x; i < n2; i += (int64_t)gridDim.x * kVecThreads) {
+    double2 zv = r2[i];
+    if (PRECOND) { const double2 dv = d2[i]; zv.x *= dv.x; zv.y *= dv.y; }
+    double2 pv = p2[i];
+    pv.x = beta * pv.x + zv.x;
+    pv.y = beta * pv.y + zv.y;
+    p2[i] = pv;
+  }
+  if ((n & 1) && leader) {
+    const int64_t i = n - 1;
+    const double zi = PRECOND ? r[i] * dinv[i] : r[i];
+    p[i] = beta * p[i] + zi;
+  }
+}
+
+static __global__ void copy_kernel(double *__restrict__ dst, const double *__restrict__ src, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+
+// sum the per-block partials of NP components into out[0..NP) (one block; feeds an all-reduce)
+template <int NP>
+static __global__ __launch_bounds__(kVecThreads) void finalize_slab_kernel(const double *slab, int nblocks, double *out) {
+  __shared__ double smem[NP * (kVecThreads / 64)];
+  double v[NP];
+  reduce_slab<NP, kVecThreads>(slab, nblocks, kSlabStride, v, smem);
+  if (threadIdx.x == 0)
+    for (int k = 0; k < NP; k++) out[k] = v[k];
+}
+
+}  // namespace mk
+
+namespace mk {
+
+static int vec_blocks(int64_t n) {
+  int64_t want = (n / 2 + kVecThreads - 1) / kVecThreads;
+  int64_t cap = (int64_t)ctx().num_cus * 8;
+  if (cap > kSlabStride) cap = kSlabStride;
+  return (int)std::max<int64_t>(1, std::min(want, cap));
+}
+
+}  // namespace mk
+
+struct mk_pcg {
+  int max_iter = 1000;      // solvers.c:83
+  double tol = 1e-6;        // solvers.c:84
+  int two_norm = 0;         // HYPRE defaults; the driver sets both to 1 (solvers.c:735,737)
+  int rel_change = 0;
+  int print_level = 0;
+  int logging = 0;
+  int precond = MK_PRECOND_NONE;
+  int check_every = 16;
+  // work space (setup)
+  int64_t n = 0;
+  double *r = nullptr, *p = nullptr, *s = nullptr;
+  double *slab1 = nullptr, *slab2 = nullptr;
+  mk::PcgState *state = nullptr;
+  double *norms = nullptr;
+  int norms_cap = 0;
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  // results
+  long long iterations = 0;
+  double rel_res_norm = 0.0;
+  int converged = 0, breakdown = 0;
+};
+

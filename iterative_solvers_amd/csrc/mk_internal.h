@@ -69,7 +69,8 @@ inline void dev_free(void *p) {
 
 // opaque C types (global namespace, matching the header's forward declarations)
 struct mk_vector {
-  int64_t n = 0;
+  int64_t n = 0;      // logical length (owned rows)
+  int64_t cap = 0;    // allocated entries (>= n; distributed vectors carry their ghost entries behind the owned ones)
   double *d = nullptr;
 };
 
@@ -169,11 +170,11 @@ __device__ __forceinline__ void block_sum(double (&v)[NP], double *smem /* NP*(T
 // Sum the per-block partials a previous kernel left in a slab (launch-boundary reduce:
 // no in-launch hand-off, so no fences).  Every block computes the same bits.
 template <int NP, int THREADS>
-__device__ __forceinline__ void reduce_slab(const double *slab, int nblocks, double (&out)[NP], double *smem) {
+__device__ __forceinline__ void reduce_slab(const double *slab, int nblocks, int stride, double (&out)[NP], double *smem) {
 #pragma unroll
   for (int k = 0; k < NP; k++) {
     double s = 0.0;
-    for (int i = threadIdx.x; i < nblocks; i += THREADS) s += slab[k * kSlabStride + i];
+    for (int i = threadIdx.x; i < nblocks; i += THREADS) s += slab[k * stride + i];
     out[k] = s;
   }
   block_sum<NP, THREADS>(out, smem);

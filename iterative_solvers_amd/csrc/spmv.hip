@@ -387,7 +387,7 @@ int launch_spmv_dot(const mk_matrix *A, const double *x, double *y, double *slab
 __global__ void finish_dot_kernel(const double *slab, int nblocks, double *out2) {
   __shared__ double smem[2 * (kThreads / 64)];
   double v[2];
-  reduce_slab<2, kThreads>(slab, nblocks, v, smem);
+  reduce_slab<2, kThreads>(slab, nblocks, kSlabStride, v, smem);
   if (threadIdx.x == 0) { out2[0] = v[0]; out2[1] = v[1]; }
 }
 

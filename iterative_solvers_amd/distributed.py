@@ -1,0 +1,211 @@
+"""Row-block distribution: ctypes front-end of the mk_comm_* / mk_dist_* entry points and the
+multi-GPU leg of bench.py.  torch.distributed is used for the rendezvous only (broadcast of the
+RCCL unique id, barriers, max-over-ranks timing); halo exchange and all-reduce run inside
+libmi355_krylov.so on RCCL communicators of its own."""
+import ctypes as C
+import json
+import os
+import time
+
+import numpy as np
+
+from . import (MkError, Matrix, PCG, Vector, _ck, init, load, synchronize)  # noqa: F401
+
+_sigs_done = False
+
+
+def _lib():
+    global _sigs_done
+    L = load()
+    if not _sigs_done:
+        P = C.c_void_p
+        L.mk_comm_get_unique_id.argtypes = [P]
+        L.mk_comm_create.argtypes = [P, C.c_int, C.c_int, C.POINTER(P)]
+        L.mk_comm_create_local.argtypes = [C.c_int, C.POINTER(P)]
+        L.mk_comm_destroy.argtypes = [P]
+        L.mk_dist_matrix_create.argtypes = [P, C.c_int64, P, P, C.POINTER(P)]
+        L.mk_dist_matrix_destroy.argtypes = [P]
+        L.mk_dist_matrix_get_info.argtypes = [P] + [C.POINTER(C.c_int64)] * 5 + [C.POINTER(C.c_int)]
+        L.mk_dist_vector_create.argtypes = [P, C.POINTER(P)]
+        L.mk_dist_spmv.argtypes = [C.c_int, C.POINTER(P), C.POINTER(P), C.POINTER(P)]
+        L.mk_dist_pcg_solve.argtypes = [C.c_int, C.POINTER(P), C.POINTER(P), C.POINTER(P), C.POINTER(P)]
+        _sigs_done = True
+    return L
+
+
+DIST_EXPORTS = ["mk_comm_get_unique_id", "mk_comm_create", "mk_comm_create_local", "mk_comm_destroy",
+                "mk_dist_matrix_create", "mk_dist_matrix_destroy", "mk_dist_matrix_get_info",
+                "mk_dist_vector_create", "mk_dist_spmv", "mk_dist_pcg_solve"]
+
+
+# ------------------------------------------------------------------ host-side helpers (no GPU)
+def slab_row_start(nx, ny, nz, world):
+    """Row blocks for a lexicographic nx*ny*nz stencil: the nnz-balanced rule of solvers.c:214-231
+    gives (to within a row) equal z-slabs, so cut at whole planes."""
+    plane = nx * ny
+    return np.array([(nz * r // world) * plane for r in range(world + 1)], dtype=np.int64)
+
+
+def even_row_start(n, world):
+    return np.array([n * r // world for r in range(world + 1)], dtype=np.int64)
+
+
+def broadcast_bytes(payload, nbytes, src=0):
+    """ship a small byte string from rank src to every rank through torch.distributed"""
+    import torch
+    import torch.distributed as dist
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+    if dist.get_rank() == src:
+        t.copy_(torch.frombuffer(bytearray(payload), dtype=torch.uint8))
+    dist.broadcast(t, src)
+    return bytes(t.cpu().numpy().tobytes())
+
+
+# ------------------------------------------------------------------------------- wrappers
+class Comm:
+    def __init__(self, handle, nranks, rank, local=False):
+        self.h, self.nranks, self.rank, self.local = handle, nranks, rank, local
+
+    @classmethod
+    def from_torch(cls):
+        """one rank per process: rank 0 draws the RCCL ids, torch.distributed ships them"""
+        import torch.distributed as dist
+        L = _lib()
+        rank, world = dist.get_rank(), dist.get_world_size()
+        buf = C.create_string_buffer(256)
+        if rank == 0:
+            _ck(L.mk_comm_get_unique_id(buf))
+        ident = broadcast_bytes(buf.raw if rank == 0 else None, 256, 0)
+        h = C.c_void_p()
+        _ck(L.mk_comm_create(ident, world, rank, C.byref(h)))
+        return cls(h, world, rank)
+
+    @classmethod
+    def local_world(cls, nranks):
+        init()
+        arr = (C.c_void_p * nranks)()
+        _ck(_lib().mk_comm_create_local(nranks, arr))
+        return [cls(C.c_void_p(arr[r]), nranks, r, True) for r in range(nranks)]
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            load().mk_comm_destroy(self.h)
+            self.h = None
+
+
+class DistMatrix:
+    def __init__(self, block, n_global, row_start, comm):
+        """block: Matrix holding this rank's rows with global column ids (consumed)"""
+        rs = np.ascontiguousarray(row_start, dtype=np.int64)
+        self.h = C.c_void_p()
+        _ck(_lib().mk_dist_matrix_create(block.h, n_global, rs.ctypes.data, comm.h if comm else None, C.byref(self.h)))
+        block.h = None      # ownership moved into the library
+        self.comm, self.row_start, self.n_global = comm, rs, n_global
+
+    def info(self):
+        v = [C.c_int64() for _ in range(5)]
+        k = C.c_int()
+        _ck(_lib().mk_dist_matrix_get_info(self.h, *[C.byref(a) for a in v], C.byref(k)))
+        return dict(n_local=v[0].value, n_ghost=v[1].value, n_offd_rows=v[2].value, nnz_diag=v[3].value,
+                    nnz_offd=v[4].value, n_neighbors=k.value)
+
+    def vector(self, fill=None, values=None):
+        v = Vector.__new__(Vector)
+        v.h = C.c_void_p()
+        _ck(_lib().mk_dist_vector_create(self.h, C.byref(v.h)))
+        v.n = int(load().mk_vector_size(v.h))
+        if values is not None:
+            v.set(values)
+        elif fill is not None:
+            v.fill(fill)
+        return v
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            load().mk_dist_matrix_destroy(self.h)
+            self.h = None
+
+
+def _arr(objs):
+    a = (C.c_void_p * len(objs))()
+    for i, o in enumerate(objs):
+        a[i] = o.h
+    return a
+
+
+def dist_spmv(As, xs, ys):
+    _ck(_lib().mk_dist_spmv(len(As), _arr(As), _arr(xs), _arr(ys)))
+
+
+def dist_pcg_solve(solvers, As, bs, xs):
+    L = _lib()
+    _ck(L.mk_dist_pcg_solve(len(As), _arr(solvers), _arr(As), _arr(bs), _arr(xs)))
+    out = []
+    for S in solvers:
+        it, nrm, cv, bd = C.c_longlong(), C.c_double(), C.c_int(), C.c_int()
+        _ck(L.mk_pcg_get_num_iterations(S.h, C.byref(it)))
+        _ck(L.mk_pcg_get_final_relative_residual_norm(S.h, C.byref(nrm)))
+        _ck(L.mk_pcg_get_converged(S.h, C.byref(cv), C.byref(bd)))
+        out.append(dict(iterations=it.value, rel_res_norm=nrm.value, converged=cv.value, breakdown=bd.value))
+    return out
+
+
+# --------------------------------------------------------------------- bench.py, N > 1 ranks
+def bench_main(args, rank, local_rank, world, workloads, hbm_peak):
+    """strong scaling of one global stencil problem over `world` GPUs (one rank each)"""
+    import torch
+    import torch.distributed as dist
+    name = args.workload or "lap7_512_cg"
+    kind, nx, ny, nz, precond, desc = workloads[name]
+    n = nx * ny * nz
+    rs = slab_row_start(nx, ny, nz, world)
+    comm = Comm.from_torch()
+    block = Matrix.stencil(kind, nx, ny, nz, row_begin=int(rs[rank]), row_end=int(rs[rank + 1]))
+    local_nnz = block.nnz
+    A = DistMatrix(block, n, rs, comm)
+    info = A.info()
+    b, x = A.vector(fill=1.0), A.vector(fill=0.0)
+
+    def run(iters):
+        S = PCG(max_iter=iters, tol=0.0, two_norm=1, rel_change=1, precond=precond, logging=0, check_every=50)
+        x.fill(0.0)
+        synchronize()
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        res = dist_pcg_solve([S], [A], [b], [x])[0]
+        synchronize()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        assert res["iterations"] == iters, res
+        return float(t.item()), res
+
+    run(max(args.warmup, 1))
+    dt, res = run(args.steps)
+    nnz_t = torch.tensor([local_nnz], dtype=torch.int64, device="cuda")
+    dist.all_reduce(nnz_t)
+    nnz = int(nnz_t.item())
+    if rank == 0:
+        ms = dt * 1e3 / args.steps
+        iter_bytes = 12 * nnz + (108 if precond else 92) * n
+        out = {
+            "metric": "CG iterations/s (fp64, fused SpMV+dot+axpy) with SpMV effective HBM GB/s",
+            "value": round(args.steps / dt, 2), "unit": "CG iterations/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": desc, "name": name, "rows": n, "nnz": nnz, "precond": "jacobi" if precond else "none",
+                       "parallelism": f"row-block x{world} (z-slabs), RCCL halo + all-reduce",
+                       "rank0": info},
+            "iteration_effective_GBps": round(iter_bytes / (ms * 1e-3) / 1e9, 1),
+            "roofline": {"bound": "hbm", "kernel": "whole CG iteration, all GPUs", "achieved": round(iter_bytes / (ms * 1e-3) / 1e9, 1),
+                         "peak": hbm_peak * world, "unit": "GB/s", "frac": round(iter_bytes / (ms * 1e-3) / 1e9 / (hbm_peak * world), 4),
+                         "traffic": None},
+            "final_rel_res_norm": res["rel_res_norm"],
+        }
+        print(json.dumps(out), flush=True)
+    dist.barrier()
+    del A, b, x
+    dist.destroy_process_group()

@@ -1,0 +1,114 @@
+"""Distributed path on ONE GPU: several logical ranks in one process ("local world"): same
+partition / ghost map / diag-offd split / solver code as over RCCL, with the exchange done by
+device copies.  Checked against the global oracle results."""
+import numpy as np
+import pytest
+
+import iterative_solvers_amd as mk
+from iterative_solvers_amd import distributed as mkd
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _blocks(rp, ci, v, n, rs, comms):
+    As = []
+    for r, cm in enumerate(comms):
+        lo, hi = int(rs[r]), int(rs[r + 1])
+        blk = mk.Matrix.from_csr(hi - lo, n, rp[lo:hi + 1] - rp[lo], ci[rp[lo]:rp[hi]], v[rp[lo]:rp[hi]])
+        As.append(mkd.DistMatrix(blk, n, rs, cm))
+    return As
+
+
+@pytest.mark.parametrize("world,cuts", [(2, None), (3, [0, 100, 1500, 1728]), (4, [0, 432, 432, 1000, 1728])])
+def test_dist_spmv_stencil(world, cuts):
+    rp, ci, v = oracle.stencil_csr(7, 12, 12, 12)
+    n = rp.size - 1
+    rng = np.random.default_rng(world)
+    v = v * rng.uniform(0.5, 1.5, v.size)
+    rs = np.array(cuts, np.int64) if cuts else mkd.slab_row_start(12, 12, 12, world)
+    comms = mkd.Comm.local_world(world)
+    As = _blocks(rp, ci, v, n, rs, comms)
+    xh = rng.normal(size=n)
+    xs = [A.vector(values=xh[rs[r]:rs[r + 1]]) for r, A in enumerate(As)]
+    ys = [A.vector(fill=-7.0) for A in As]
+    mkd.dist_spmv(As, xs, ys)
+    got = np.concatenate([y.get() for y in ys])
+    ref = oracle.csr_spmv(rp, ci, v, xh)
+    assert np.abs(got - ref).max() <= 1e-12 * np.abs(ref).max()
+    i0 = As[0].info()
+    assert i0["n_local"] == rs[1] and i0["nnz_diag"] + i0["nnz_offd"] == rp[rs[1]]
+    if cuts is None and world == 2:
+        assert i0["n_ghost"] == 144 and i0["n_offd_rows"] == 144 and i0["n_neighbors"] == 1
+
+
+def test_dist_spmv_all_to_all_rmat():
+    scale, ne, world = 11, 1 << 15, 4
+    r, c, v = oracle.rmat_coo(scale, ne, seed=7)
+    n = 1 << scale
+    rp, ci, val = oracle.coo_to_csr(n, r, c, v)
+    rs = mk.partition_rows(rp, world)                 # nnz-balanced blocks (solvers.c:214-231)
+    comms = mkd.Comm.local_world(world)
+    As = _blocks(rp, ci, val, n, rs, comms)
+    assert max(A.info()["n_neighbors"] for A in As) == world - 1
+    xh = np.random.default_rng(3).normal(size=n)
+    xs = [A.vector(values=xh[rs[k]:rs[k + 1]]) for k, A in enumerate(As)]
+    ys = [A.vector() for A in As]
+    mkd.dist_spmv(As, xs, ys)
+    got = np.concatenate([y.get() for y in ys])
+    ref = oracle.csr_spmv(rp, ci, val, xh)
+    mag = oracle.csr_spmv(rp, ci, np.abs(val), np.abs(xh))
+    assert (np.abs(got - ref) / np.maximum(mag, 1e-300)).max() <= 1e-12
+
+
+@pytest.mark.parametrize("world,precond", [(1, 0), (2, 1), (4, 0), (8, 1)])
+def test_dist_pcg_matches_oracle(world, precond):
+    rp, ci, v = oracle.stencil_csr(7, 16, 16, 24)
+    n = rp.size - 1
+    rng = np.random.default_rng(5)
+    d = rng.uniform(1.0, 20.0, n)
+    rows = np.repeat(np.arange(n), np.diff(rp))
+    v = v * np.sqrt(d[rows] * d[ci])
+    bh = rng.normal(size=n)
+    o = oracle.pcg(rp, ci, v, bh, tol=1e-9, precond=precond, maxit=3000, want_norms=True)
+    rs = mkd.slab_row_start(16, 16, 24, world)
+    comms = mkd.Comm.local_world(world) if world > 1 else [None]
+    As = _blocks(rp, ci, v, n, rs, comms)
+    bs = [A.vector(values=bh[rs[k]:rs[k + 1]]) for k, A in enumerate(As)]
+    xs = [A.vector(fill=0.0) for A in As]
+    Ss = [mk.PCG(max_iter=3000, tol=1e-9, precond=precond, logging=1, check_every=9) for _ in As]
+    res = mkd.dist_pcg_solve(Ss, As, bs, xs)
+    assert all(q == res[0] for q in res)
+    assert res[0]["converged"] == 1 and abs(res[0]["iterations"] - o["iterations"]) <= 2
+    xg = np.concatenate([x.get() for x in xs])
+    assert np.linalg.norm(xg - o["x"]) <= 1e-6 * np.linalg.norm(o["x"])
+    hist = Ss[0].residual_history(4000)
+    m = min(hist.size, o["rel_norms"].size, 30)
+    assert np.allclose(hist[:m], o["rel_norms"][:m], rtol=1e-8)
+
+
+def test_dist_pcg_maxit_and_empty_rank():
+    rp, ci, v = oracle.stencil_csr(5, 20, 20)
+    n = rp.size - 1
+    rs = np.array([0, 150, 150, 400], np.int64)       # the middle rank owns nothing
+    comms = mkd.Comm.local_world(3)
+    As = _blocks(rp, ci, v, n, rs, comms)
+    bs = [A.vector(fill=1.0) for A in As]
+    xs = [A.vector(fill=0.0) for A in As]
+    Ss = [mk.PCG(max_iter=7, tol=1e-14) for _ in As]
+    res = mkd.dist_pcg_solve(Ss, As, bs, xs)
+    o = oracle.pcg(rp, ci, v, np.ones(n), tol=1e-14, maxit=7)
+    assert res[0]["iterations"] == 7 and res[0]["converged"] == 0
+    assert np.isclose(res[0]["rel_res_norm"], o["rel_res_norm"], rtol=1e-9)
+    assert np.allclose(np.concatenate([x.get() for x in xs]), o["x"], rtol=1e-9)
+
+
+def test_dist_errors():
+    rp, ci, v = oracle.stencil_csr(5, 8, 8)
+    comms = mkd.Comm.local_world(2)
+    blk = mk.Matrix.from_csr(32, 64, rp[:33], ci[:rp[32]], v[:rp[32]])
+    with pytest.raises(mk.MkError):
+        mkd.DistMatrix(blk, 64, np.array([0, 30, 64], np.int64), comms[0])     # block size != row range
+    A0 = mkd.DistMatrix(mk.Matrix.from_csr(32, 64, rp[:33], ci[:rp[32]], v[:rp[32]]), 64, np.array([0, 32, 64], np.int64), comms[0])
+    with pytest.raises(mk.MkError):
+        mkd.dist_spmv([A0], [A0.vector()], [A0.vector()])                      # rank 1 never created its block
