@@ -68,6 +68,8 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "MK_BENCH_DEVICE" in os.environ:     # rehearsal of the N>1 path on a box with fewer GPUs
+        local_rank = int(os.environ["MK_BENCH_DEVICE"])
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch through torch.distributed.run")

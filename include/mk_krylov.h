@@ -186,6 +186,8 @@ int mk_comm_get_unique_id(void *id256);
 int mk_comm_create(const void *id256, int nranks, int rank, mk_comm **comm);   /* MPI_Init + MPI_Comm_rank/size (solvers.c:68-70) */
 /* several logical ranks inside ONE process on one GPU (tests): exchange = device copies */
 int mk_comm_create_local(int nranks, mk_comm **comms);
+/* collective check of every RCCL call the solver relies on (ring send/recv, all-gather, all-reduce) */
+int mk_comm_self_test(mk_comm *comm);
 int mk_comm_destroy(mk_comm *comm);
 /* A holds rows [row_start[rank], row_start[rank+1]) of the global operator with GLOBAL column
  * ids (ncols = n_global) and is consumed.  Collective. comm may be NULL for a single rank. */

@@ -60,7 +60,7 @@ EXPORTS = [
     "mk_jacobi_setup", "mk_jacobi_solve", "mk_jacobi_get_num_iterations",
     "mk_jacobi_get_final_relative_residual_norm", "mk_jacobi_get_converged", "mk_jacobi_destroy",
     "mk_partition_rows",
-    "mk_comm_get_unique_id", "mk_comm_create", "mk_comm_create_local", "mk_comm_destroy",
+    "mk_comm_get_unique_id", "mk_comm_create", "mk_comm_create_local", "mk_comm_self_test", "mk_comm_destroy",
     "mk_dist_matrix_create", "mk_dist_matrix_destroy", "mk_dist_matrix_get_info",
     "mk_dist_vector_create", "mk_dist_spmv", "mk_dist_pcg_solve",
 ]

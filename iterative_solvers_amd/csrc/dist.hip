@@ -369,7 +369,7 @@ static int build_plan_local(LocalWorld *W) {
 // v[r] has n_local owned entries followed by n_ghost ghost entries
 static int halo_exchange(int R, mk_dist_matrix **A, double **v, bool overlap) {
   Context &c = ctx();
-  if (A[0]->nranks == 1) return MK_OK;
+  if (A[0]->comm == nullptr) return MK_OK;
   if (A[0]->comm->local) {
     for (int r = 0; r < R; r++)
       if (A[r]->n_send) hipLaunchKernelGGL(pack_kernel, dim3(grid1(A[r]->n_send, 1024)), dim3(256), 0, c.stream, A[r]->n_send, A[r]->send_idx, v[r], A[r]->sendbuf);
@@ -399,14 +399,14 @@ static int halo_exchange(int R, mk_dist_matrix **A, double **v, bool overlap) {
 }
 
 static int halo_wait(mk_dist_matrix *D, bool overlap) {
-  if (D->nranks == 1 || D->comm->local || !overlap) return MK_OK;
+  if (D->comm == nullptr || D->comm->local || !overlap) return MK_OK;
   MK_HIP(hipStreamWaitEvent(ctx().stream, D->comm->ev_halo, 0));
   return MK_OK;
 }
 
 static int all_reduce(int R, mk_dist_matrix **A, double **bufs, int count) {
   Context &c = ctx();
-  if (A[0]->nranks == 1) return MK_OK;
+  if (A[0]->comm == nullptr) return MK_OK;
   if (A[0]->comm->local) {
     LocalWorld *W = A[0]->comm->world;
     MK_HIP(hipMemcpyAsync(W->d_ptrs, bufs, sizeof(double *) * R, hipMemcpyHostToDevice, c.stream));
@@ -495,6 +495,48 @@ int mk_comm_create_local(int nranks, mk_comm **comms) {
   return MK_OK;
 }
 
+__global__ void selftest_fill_kernel(double *a, int n, int rank) {
+  if (threadIdx.x < n) a[threadIdx.x] = 1000.0 * rank + threadIdx.x;
+}
+
+// exercises every RCCL entry point the solver uses (grouped send/recv to itself, all-gather,
+// all-reduce) on a few doubles and checks the values; collective
+int mk_comm_self_test(mk_comm *cm) {
+  MK_REQUIRE_INIT();
+  if (!cm) return fail(MK_ERR_INVALID, "mk_comm_self_test: null communicator");
+  if (cm->local) return MK_OK;
+  Context &c = ctx();
+  const int n = 8, P = cm->nranks;
+  double *a = nullptr, *b = nullptr, *g = nullptr;
+  MK_TRY(dev_alloc(&a, n));
+  MK_TRY(dev_alloc(&b, n));
+  MK_TRY(dev_alloc(&g, (size_t)n * P));
+  hipLaunchKernelGGL(selftest_fill_kernel, dim3(1), dim3(64), 0, c.stream, a, n, cm->rank);
+  MK_HIP(hipMemsetAsync(b, 0, sizeof(double) * n, c.stream));
+  // ring: send to the next rank, receive from the previous one (to itself when alone)
+  const int next = (cm->rank + 1) % P, prev = (cm->rank + P - 1) % P;
+  MK_NCCL(g_rccl.GroupStart());
+  MK_NCCL(g_rccl.Send(a, n, ncclDouble, next, cm->p2p, c.stream));
+  MK_NCCL(g_rccl.Recv(b, n, ncclDouble, prev, cm->p2p, c.stream));
+  MK_NCCL(g_rccl.GroupEnd());
+  MK_NCCL(g_rccl.AllGather(a, g, n, ncclDouble, cm->coll, c.stream));
+  MK_NCCL(g_rccl.AllReduce(a, a, n, ncclDouble, ncclSum, cm->coll, c.stream));
+  std::vector<double> ha(n), hb(n), hg((size_t)n * P);
+  MK_HIP(hipMemcpyAsync(ha.data(), a, sizeof(double) * n, hipMemcpyDeviceToHost, c.stream));
+  MK_HIP(hipMemcpyAsync(hb.data(), b, sizeof(double) * n, hipMemcpyDeviceToHost, c.stream));
+  MK_HIP(hipMemcpyAsync(hg.data(), g, sizeof(double) * n * P, hipMemcpyDeviceToHost, c.stream));
+  MK_HIP(hipStreamSynchronize(c.stream));
+  dev_free(a); dev_free(b); dev_free(g);
+  for (int k = 0; k < n; k++) {
+    const double want_sum = 1000.0 * (P * (P - 1) / 2) + (double)P * k;
+    if (hb[k] != 1000.0 * prev + k) return fail(MK_ERR_COMM, "mk_comm_self_test: send/recv delivered %g, expected %g", hb[k], 1000.0 * prev + k);
+    if (ha[k] != want_sum) return fail(MK_ERR_COMM, "mk_comm_self_test: all-reduce gave %g, expected %g", ha[k], want_sum);
+    for (int q = 0; q < P; q++)
+      if (hg[(size_t)q * n + k] != 1000.0 * q + k) return fail(MK_ERR_COMM, "mk_comm_self_test: all-gather slot wrong");
+  }
+  return MK_OK;
+}
+
 int mk_comm_destroy(mk_comm *cm) {
   if (!cm) return MK_OK;
   if (ctx().ready) (void)hipDeviceSynchronize();
@@ -520,7 +562,7 @@ int mk_dist_matrix_create(mk_matrix *A, int64_t n_global, const int64_t *row_sta
   MK_REQUIRE_INIT();
   if (!A || !row_start || !out) return fail(MK_ERR_INVALID, "mk_dist_matrix_create: null argument");
   const int P = comm ? comm->nranks : 1, me = comm ? comm->rank : 0;
-  if (P > 1 && !comm->local && !comm->coll) return fail(MK_ERR_INVALID, "mk_dist_matrix_create: communicator not initialised");
+  if (comm && !comm->local && !comm->coll) return fail(MK_ERR_INVALID, "mk_dist_matrix_create: communicator not initialised");
   if (n_global > 0x7fffffffLL) return fail(MK_ERR_UNSUPPORTED, "mk_dist_matrix_create: more than 2^31-1 global columns");
   if (row_start[0] != 0 || row_start[P] != n_global) return fail(MK_ERR_INVALID, "mk_dist_matrix_create: row_start must run from 0 to n_global");
   for (int q = 0; q < P; q++)
@@ -536,9 +578,10 @@ int mk_dist_matrix_create(mk_matrix *A, int64_t n_global, const int64_t *row_sta
   D->n_local = D->row_end - D->row_begin;
   int rc = split_block(A, D);
   if (rc == MK_OK) {
-    if (P == 1) {
+    if (comm == nullptr) {
+      if (P != 1) rc = fail(MK_ERR_INVALID, "mk_dist_matrix_create: more than one rank needs a communicator");
       D->send_cnt.assign(1, 0);
-      rc = finish_send_plan(D);
+      if (rc == MK_OK) rc = finish_send_plan(D);
       D->plan_ready = true;
     } else if (comm->local) {
       LocalWorld *W = comm->world;
@@ -643,7 +686,7 @@ int mk_dist_pcg_solve(int R, mk_pcg **solvers, mk_dist_matrix **A, mk_vector **b
     if (solvers[r]->max_iter != S0->max_iter || solvers[r]->tol != S0->tol || solvers[r]->precond != S0->precond)
       return fail(MK_ERR_INVALID, "mk_dist_pcg_solve: ranks disagree on solver settings");
   }
-  const bool rccl = A[0]->nranks > 1 && !A[0]->comm->local;
+  const bool rccl = A[0]->comm != nullptr && !A[0]->comm->local;
   const bool want_norms = S0->logging > 0 || S0->print_level > 0;
   std::vector<DistWork> W(R);
   std::vector<double *> pv(R), xv(R), bufs(R);

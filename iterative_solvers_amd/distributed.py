@@ -23,6 +23,7 @@ def _lib():
         L.mk_comm_create.argtypes = [P, C.c_int, C.c_int, C.POINTER(P)]
         L.mk_comm_create_local.argtypes = [C.c_int, C.POINTER(P)]
         L.mk_comm_destroy.argtypes = [P]
+        L.mk_comm_self_test.argtypes = [P]
         L.mk_dist_matrix_create.argtypes = [P, C.c_int64, P, P, C.POINTER(P)]
         L.mk_dist_matrix_destroy.argtypes = [P]
         L.mk_dist_matrix_get_info.argtypes = [P] + [C.POINTER(C.c_int64)] * 5 + [C.POINTER(C.c_int)]
@@ -33,7 +34,7 @@ def _lib():
     return L
 
 
-DIST_EXPORTS = ["mk_comm_get_unique_id", "mk_comm_create", "mk_comm_create_local", "mk_comm_destroy",
+DIST_EXPORTS = ["mk_comm_get_unique_id", "mk_comm_create", "mk_comm_create_local", "mk_comm_self_test", "mk_comm_destroy",
                 "mk_dist_matrix_create", "mk_dist_matrix_destroy", "mk_dist_matrix_get_info",
                 "mk_dist_vector_create", "mk_dist_spmv", "mk_dist_pcg_solve"]
 
@@ -80,6 +81,20 @@ class Comm:
         h = C.c_void_p()
         _ck(L.mk_comm_create(ident, world, rank, C.byref(h)))
         return cls(h, world, rank)
+
+    @classmethod
+    def single_rccl(cls):
+        """a one-rank RCCL communicator (drives the RCCL code path on a single GPU)"""
+        init()
+        L = _lib()
+        buf = C.create_string_buffer(256)
+        _ck(L.mk_comm_get_unique_id(buf))
+        h = C.c_void_p()
+        _ck(L.mk_comm_create(buf.raw, 1, 0, C.byref(h)))
+        return cls(h, 1, 0)
+
+    def self_test(self):
+        _ck(_lib().mk_comm_self_test(self.h))
 
     @classmethod
     def local_world(cls, nranks):
@@ -161,6 +176,7 @@ def bench_main(args, rank, local_rank, world, workloads, hbm_peak):
     n = nx * ny * nz
     rs = slab_row_start(nx, ny, nz, world)
     comm = Comm.from_torch()
+    comm.self_test()
     block = Matrix.stencil(kind, nx, ny, nz, row_begin=int(rs[rank]), row_end=int(rs[rank + 1]))
     local_nnz = block.nnz
     A = DistMatrix(block, n, rs, comm)

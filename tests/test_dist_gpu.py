@@ -112,3 +112,23 @@ def test_dist_errors():
     A0 = mkd.DistMatrix(mk.Matrix.from_csr(32, 64, rp[:33], ci[:rp[32]], v[:rp[32]]), 64, np.array([0, 32, 64], np.int64), comms[0])
     with pytest.raises(mk.MkError):
         mkd.dist_spmv([A0], [A0.vector()], [A0.vector()])                      # rank 1 never created its block
+
+
+def test_rccl_code_path_single_rank():
+    """RCCL itself refuses two ranks on one GPU, so the real communicator is exercised with one
+    rank: dlopen + symbol binding, comm init, grouped send/recv, all-gather, all-reduce, and the
+    solver running its RCCL branch (communication stream, events, all-reduced scalars)."""
+    comm = mkd.Comm.single_rccl()
+    comm.self_test()
+    rp, ci, v = oracle.stencil_csr(7, 14, 14, 14)
+    n = rp.size - 1
+    A = mkd.DistMatrix(mk.Matrix.from_csr(n, n, rp, ci, v), n, np.array([0, n], np.int64), comm)
+    b, x = A.vector(fill=1.0), A.vector(fill=0.0)
+    S = mk.PCG(max_iter=500, tol=1e-8, precond=1)
+    res = mkd.dist_pcg_solve([S], [A], [b], [x])[0]
+    o = oracle.pcg(rp, ci, v, np.ones(n), tol=1e-8, precond=1, maxit=500)
+    assert res["converged"] == 1 and abs(res["iterations"] - o["iterations"]) <= 2
+    assert np.linalg.norm(x.get() - o["x"]) <= 1e-6 * np.linalg.norm(o["x"])
+    y = A.vector()
+    mkd.dist_spmv([A], [x], [y])
+    assert np.allclose(y.get(), oracle.csr_spmv(rp, ci, v, x.get()), rtol=1e-12, atol=1e-12)
