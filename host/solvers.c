@@ -1,0 +1,188 @@
+/*
+ * solvers.c -- host driver with the reference's command line and output lines
+ * (src/solvers.c:98-152 flags, :762-772 result lines), calling libmi355_krylov.so where the
+ * reference calls HYPRE.  One process drives one MI355X.
+ *
+ *   -solver 50  PCG, no preconditioner, two-norm + rel_change stopping   (solvers.c:724-776)
+ *   -solver 51  PCG with diagonal scaling      (extension)
+ *   -solver 70  plain Jacobi iteration          (extension)
+ * The other ids of the reference (AMG, ILU, ParaSails, GMRES, BiCGSTAB, ...; solvers.c:465-1548)
+ * are HYPRE preconditioner stacks outside this library's scope and are refused by name.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include "sparse_matrix.h"
+
+static double now_s(void) {
+  struct timespec t;
+  clock_gettime(CLOCK_MONOTONIC, &t);
+  return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec;
+}
+
+#define CK(call)                                                                  \
+  do {                                                                            \
+    int rc_ = (call);                                                             \
+    if (rc_ != 0) {                                                               \
+      fprintf(stderr, "%s failed (%d): %s\n", #call, rc_, mk_last_error_string()); \
+      return 1;                                                                   \
+    }                                                                             \
+  } while (0)
+
+static void usage(const char *argv0) {
+  printf("\nUsage: %s [<options>]\n\n", argv0);
+  printf("  -mtx <matrix.mtx>      : matrix market path\n");
+  printf("  -b <vector.mtx>        : RHS matrix market format path (default: all ones)\n");
+  printf("  -x <vector.mtx>        : initial guess (default: zeros)\n");
+  printf("  -maxit <n>             : Max number of iterations (default 1000)\n");
+  printf("  -tol <t>               : tolerance (default 1e-6)\n");
+  printf("  -log <n>               : printing level out of the solver\n");
+  printf("  -precond_log <n>       : accepted, unused (no HYPRE preconditioners here)\n");
+  printf("  -niter <n>             : solve problem n times (later solves start from the previous x)\n");
+  printf("  -dev <id>              : GPU to use (default 0)\n");
+  printf("  -solver <ID>           : solver ID\n");
+  printf("                           50 - PCG\n");
+  printf("                           51 - PCG + diagonal scaling\n");
+  printf("                           70 - Jacobi iteration\n");
+  printf("  -print_system          : write the assembled CSR back to IJ.out.A as text\n\n");
+}
+
+int main(int argc, char *argv[]) {
+  int maxit = 1000, prnt_info = 2, precond_log = 1, niter = 1, solver_id = 0, print_system = 0, dev = 0, comp_id = 0;
+  double tol = 1e-6;
+  const char *mtx = NULL, *bfile = NULL, *xfile = NULL, *pow_file = NULL;
+  (void)precond_log; (void)comp_id; (void)pow_file;
+  for (int i = 1; i < argc;) {
+    const char *a = argv[i];
+    const int has = i + 1 < argc;
+    if (!strcmp(a, "-maxit") && has) { maxit = atoi(argv[i + 1]); i += 2; }
+    else if (!strcmp(a, "-tol") && has) { tol = atof(argv[i + 1]); i += 2; }
+    else if (!strcmp(a, "-log") && has) { prnt_info = atoi(argv[i + 1]); i += 2; }
+    else if (!strcmp(a, "-niter") && has) { niter = atoi(argv[i + 1]); i += 2; }
+    else if (!strcmp(a, "-padding")) { i += 1; }                       /* parsed and ignored by the reference too (:115-117) */
+    else if (!strcmp(a, "-id") && has) { comp_id = atoi(argv[i + 1]); i += 2; }
+    else if (!strcmp(a, "-precond_log") && has) { precond_log = atoi(argv[i + 1]); i += 2; }
+    else if (!strcmp(a, "-solver") && has) { solver_id = atoi(argv[i + 1]); i += 2; }
+    else if (!strcmp(a, "-mtx") && has) { mtx = argv[i + 1]; i += 2; }
+    else if (!strcmp(a, "-p") && has) { pow_file = argv[i + 1]; i += 2; }
+    else if (!strcmp(a, "-b") && has) { bfile = argv[i + 1]; i += 2; }
+    else if (!strcmp(a, "-x") && has) { xfile = argv[i + 1]; i += 2; }
+    else if (!strcmp(a, "-dev") && has) { dev = atoi(argv[i + 1]); i += 2; }
+    else if (!strcmp(a, "-print_system")) { print_system = 1; i += 1; }
+    else if (!strcmp(a, "-help")) { usage(argv[0]); return 0; }
+    else i += 1;                                                      /* unknown flags are skipped (:149-151) */
+  }
+  if (!mtx) { usage(argv[0]); return 1; }
+  if (solver_id != 50 && solver_id != 51 && solver_id != 70) {
+    printf("Invalid solver id specified.\n");
+    fprintf(stderr, "solver %d is a HYPRE preconditioner/solver stack outside this library; use 50, 51 or 70\n", solver_id);
+    return 1;
+  }
+
+  CK(mk_init(dev));                                                   /* HYPRE_Init (:79) */
+
+  SparseMatrixCOO coo;
+  double t0 = now_s();
+  if (fast_load_from_mtx_file(mtx, &coo) != 0) return 1;              /* :196 */
+  double t1 = now_s();
+  if (coo.nrows != coo.ncolumns) { fprintf(stderr, "matrix is %u x %u: a square system is required\n", coo.nrows, coo.ncolumns); return 1; }
+  /* the reference sorts on the host (:198) and hands slices to HYPRE (:330); here the
+   * unsorted COO goes to the device, which sorts, converts and keeps the CSR */
+  mk_matrix *A = NULL;
+  CK(mk_matrix_from_coo(&coo, &A));                                   /* :289-374 */
+  double t2 = now_s();
+  fprintf(stderr, "Finish reading and sorting of COO data\n");        /* :212 */
+  fprintf(stderr, "Dataset reading time: %lg msec, device assembly: %lg msec\n", (t1 - t0) * 1e3, (t2 - t1) * 1e3);
+  const unsigned int n = coo.nrows;
+  free_coo(&coo);                                                     /* :376-378 */
+
+  mk_vector *b = NULL, *x = NULL;
+  CK(mk_vector_create(n, &b));
+  CK(mk_vector_create(n, &x));
+  if (bfile) {                                                        /* :413-418 */
+    double *h = NULL; unsigned int m = 0;
+    if (fast_load_from_array_file(bfile, &h, &m) != 0) return 1;
+    if (m < n) { fprintf(stderr, "%s holds %u values, %u needed\n", bfile, m, n); return 1; }
+    CK(mk_vector_set(b, h));
+    free(h);
+  } else {
+    CK(mk_vector_fill(b, 1.0));                                       /* :404-412 */
+  }
+  if (xfile) {                                                        /* :431-436 */
+    double *h = NULL; unsigned int m = 0;
+    if (fast_load_from_array_file(xfile, &h, &m) != 0) return 1;
+    if (m < n) { fprintf(stderr, "%s holds %u values, %u needed\n", xfile, m, n); return 1; }
+    CK(mk_vector_set(x, h));
+    free(h);
+  } else {
+    CK(mk_vector_fill(x, 0.0));                                       /* :420-430 */
+  }
+  if (print_system) {                                                 /* :450-454 */
+    SparseMatrixCSR csr;
+    CK(mk_matrix_get_csr(A, &csr));
+    FILE *f = fopen("IJ.out.A", "w");
+    if (f) {
+      fprintf(f, "%u %u %u\n", csr.nrows, csr.ncolumns, csr.nnz);
+      for (unsigned int r = 0; r < csr.nrows; r++)
+        for (int k = csr.row_pointers[r]; k < csr.row_pointers[r + 1]; k++)
+          fprintf(f, "%u %d %.17g\n", r, csr.column_indices[k], csr.values[k]);
+      fclose(f);
+    }
+    free_csr(&csr);
+  }
+
+  long long num_iterations = 0;
+  double final_res_norm = 0.0, walltime;
+  if (solver_id == 50 || solver_id == 51) {
+    mk_pcg *solver = NULL;
+    CK(mk_pcg_create(&solver));                                       /* :729 */
+    CK(mk_pcg_set_max_iter(solver, maxit));                           /* :732 */
+    CK(mk_pcg_set_tol(solver, tol));                                  /* :734 */
+    CK(mk_pcg_set_two_norm(solver, 1));                               /* :735 */
+    CK(mk_pcg_set_rel_change(solver, 1));                             /* :737 */
+    CK(mk_pcg_set_print_level(solver, prnt_info));                    /* :742 */
+    CK(mk_pcg_set_logging(solver, 1));                                /* :744 */
+    if (solver_id == 51) CK(mk_pcg_set_precond(solver, MK_PRECOND_JACOBI));
+    CK(mk_pcg_setup(solver, A, b, x));                                /* :747 */
+    CK(mk_synchronize());
+    double t = -now_s();                                              /* :752 */
+    for (int i = 0; i < niter; i++) CK(mk_pcg_solve(solver, A, b, x)); /* :753-754 */
+    CK(mk_synchronize());
+    t += now_s();
+    walltime = t;
+    printf("\nPCG Solve time = %f seconds\n\n", walltime);            /* :762 */
+    CK(mk_pcg_get_num_iterations(solver, &num_iterations));           /* :765 */
+    CK(mk_pcg_get_final_relative_residual_norm(solver, &final_res_norm)); /* :766 */
+    CK(mk_pcg_destroy(solver));                                       /* :775 */
+  } else {
+    mk_jacobi *solver = NULL;
+    CK(mk_jacobi_create(&solver));
+    CK(mk_jacobi_set_max_iter(solver, maxit));
+    CK(mk_jacobi_set_tol(solver, tol));
+    CK(mk_jacobi_setup(solver, A, b, x));
+    CK(mk_synchronize());
+    double t = -now_s();
+    for (int i = 0; i < niter; i++) CK(mk_jacobi_solve(solver, A, b, x));
+    CK(mk_synchronize());
+    t += now_s();
+    walltime = t;
+    printf("\nJacobi Solve time = %f seconds\n\n", walltime);
+    CK(mk_jacobi_get_num_iterations(solver, &num_iterations));
+    CK(mk_jacobi_get_final_relative_residual_norm(solver, &final_res_norm));
+    CK(mk_jacobi_destroy(solver));
+  }
+  printf("\n");
+  printf("Iterations = %lld\n", num_iterations);                      /* :770 */
+  printf("Final Relative Residual Norm = %e\n", final_res_norm);      /* :771 */
+  printf("\n");
+  /* extra lines the reference does not print: rate, for scripts/grep_res.sh-style scraping */
+  if (walltime > 0.0 && num_iterations > 0) printf("Iterations per second = %f\n", (double)num_iterations * niter / walltime);
+
+  mk_vector_destroy(b);
+  mk_vector_destroy(x);
+  mk_matrix_destroy(A);                                               /* :1555 */
+  mk_finalize();                                                      /* :1560 */
+  return 0;
+}

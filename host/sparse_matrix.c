@@ -1,0 +1,139 @@
+/* sparse_matrix.c -- host loader of the driver (see sparse_matrix.h). */
+#include "sparse_matrix.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "mmio.h"
+
+size_t get_multiple_of_align_size(size_t size) { return (size + align_size - 1) / align_size * align_size; }
+
+static void *aalloc(size_t bytes) {
+  if (bytes == 0) bytes = align_size;
+  return aligned_alloc(align_size, get_multiple_of_align_size(bytes));
+}
+
+void free_coo(SparseMatrixCOO *m) {
+  free(m->values); free(m->rows); free(m->columns);
+  m->values = NULL; m->rows = NULL; m->columns = NULL;
+}
+
+void free_csr(SparseMatrixCSR *m) {
+  free(m->values); free(m->column_indices); free(m->row_pointers);
+  m->values = NULL; m->column_indices = NULL; m->row_pointers = NULL;
+}
+
+/* Reference semantics kept (sparse_matrix.c:228-376):
+ *  - coordinate files with real or pattern field only (:250-255);
+ *  - indices turn 0-based (:297-299); pattern entries get 1.0 (:322,367);
+ *  - symmetric: an off-diagonal (r,c,v) is followed at once by (c,r,v); the arrays are
+ *    sized for 2*entries (:279-312);
+ *  - nothing is filtered or merged: explicit zeros and duplicates stay (:372).
+ * Differences: errors are returned, not exit()ed; a short file is an error instead of a
+ * read past the buffer. */
+int fast_load_from_mtx_file(const char *path, SparseMatrixCOO *coo) {
+  FILE *f = fopen(path, "r");
+  if (!f) { fprintf(stderr, "Could not open file: %s \n", path); return 1; }
+  MM_typecode tc;
+  if (mm_read_banner(f, &tc) != 0) { fprintf(stderr, "Could not process Matrix Market banner.\n"); fclose(f); return 2; }
+  if ((!mm_is_real(tc) && !mm_is_pattern(tc)) || !mm_is_matrix(tc) || !mm_is_sparse(tc)) {
+    fprintf(stderr, "Market Market type: [%s] not supported\n", mm_typecode_to_str(tc));
+    fclose(f);
+    return 3;
+  }
+  unsigned int nrows, ncols, entries;
+  if (mm_read_mtx_crd_size(f, &nrows, &ncols, &entries) != 0) {
+    fprintf(stderr, "Error while reading matrix dimension sizes.\n");
+    fclose(f);
+    return 4;
+  }
+  const long here = ftell(f);
+  fseek(f, 0, SEEK_END);
+  const long len = ftell(f) - here;
+  fseek(f, here, SEEK_SET);
+  char *text = (char *)malloc((size_t)len + 1);
+  if (!text) { fclose(f); return 5; }
+  const size_t got = fread(text, 1, (size_t)len, f);
+  text[got] = '\0';
+  fclose(f);
+
+  const int sym = mm_is_symmetric(tc), pat = mm_is_pattern(tc);
+  const size_t cap = (size_t)entries * (sym ? 2 : 1);
+  coo->nrows = nrows;
+  coo->ncolumns = ncols;
+  coo->rows = (int *)aalloc(cap * sizeof(int));
+  coo->columns = (int *)aalloc(cap * sizeof(int));
+  coo->values = (double *)aalloc(cap * sizeof(double));
+  if (!coo->rows || !coo->columns || !coo->values) { free(text); free_coo(coo); return 5; }
+  unsigned int k = 0;
+  char *p = text, *q;
+  for (unsigned int i = 0; i < entries; i++) {
+    const unsigned long r = strtoul(p, &q, 10);
+    if (q == p) { fprintf(stderr, "%s: entry %u of %u missing\n", path, i + 1, entries); free(text); free_coo(coo); return 6; }
+    p = q;
+    const unsigned long c = strtoul(p, &q, 10);
+    if (q == p) { fprintf(stderr, "%s: entry %u truncated\n", path, i + 1); free(text); free_coo(coo); return 6; }
+    p = q;
+    double v = 1.0;
+    if (!pat) {
+      v = strtod(p, &q);
+      if (q == p) { fprintf(stderr, "%s: entry %u has no value\n", path, i + 1); free(text); free_coo(coo); return 6; }
+      p = q;
+    }
+    coo->rows[k] = (int)(r - 1);
+    coo->columns[k] = (int)(c - 1);
+    coo->values[k] = v;
+    k++;
+    if (sym && r != c) {
+      coo->rows[k] = (int)(c - 1);
+      coo->columns[k] = (int)(r - 1);
+      coo->values[k] = v;
+      k++;
+    }
+  }
+  coo->nnz = k;
+  free(text);
+  return 0;
+}
+
+/* sparse_matrix.c:34-90: `m` values, one per line, of a Matrix Market array file (only the
+ * first column is meaningful in the reference as well: it ignores n, :72-76).  The validity
+ * test uses || where the reference has &&. */
+int fast_load_from_array_file(const char *path, double **vals, unsigned int *count) {
+  FILE *f = fopen(path, "r");
+  if (!f) { fprintf(stderr, "Could not open file: %s \n", path); return 1; }
+  MM_typecode tc;
+  if (mm_read_banner(f, &tc) != 0) { fprintf(stderr, "Could not process Matrix Market banner.\n"); fclose(f); return 2; }
+  if (!mm_is_real(tc) || !mm_is_array(tc)) {
+    fprintf(stderr, "Market Market type: [%s] not array\n", mm_typecode_to_str(tc));
+    fclose(f);
+    return 3;
+  }
+  unsigned int m, n;
+  if (mm_read_mtx_array_size(f, &m, &n) != 0) { fprintf(stderr, "Error while reading matrix dimension sizes.\n"); fclose(f); return 4; }
+  *vals = (double *)aalloc((size_t)m * sizeof(double));
+  if (!*vals) { fclose(f); return 5; }
+  for (unsigned int i = 0; i < m; i++)
+    if (fscanf(f, "%lg", &(*vals)[i]) != 1) { fprintf(stderr, "%s: value %u of %u missing\n", path, i + 1, m); fclose(f); free(*vals); *vals = NULL; return 6; }
+  if (count) *count = m;
+  fclose(f);
+  return 0;
+}
+
+/* device stable sort by row: sparse_matrix.c:419-529 */
+int sort_coo_row(const SparseMatrixCOO *coo, SparseMatrixCOO *sorted) {
+  int rc = mk_sort_coo_row(coo, sorted);
+  if (rc) fprintf(stderr, "sort_coo_row: %s\n", mk_last_error_string());
+  return rc;
+}
+
+/* device COO -> CSR: sparse_matrix.c:649-742 */
+int convert_coo_to_csr(const SparseMatrixCOO *coo, SparseMatrixCSR *csr, int free_coo_flag) {
+  int rc = mk_coo_to_csr(coo, csr);
+  if (rc) fprintf(stderr, "convert_coo_to_csr: %s\n", mk_last_error_string());
+  if (rc == 0 && free_coo_flag) {
+    free(coo->values); free(coo->rows); free(coo->columns);
+  }
+  return rc;
+}

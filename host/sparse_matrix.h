@@ -1,0 +1,31 @@
+/*
+ * sparse_matrix.h -- host API of the driver: the reference's containers and entry points
+ * (src/sparse_matrix.h:24-66) with the heavy lifting moved into libmi355_krylov.so.
+ *   fast_load_from_mtx_file   : host text parser (sparse_matrix.c:228-376 semantics)
+ *   fast_load_from_array_file : vector files for -b / -x (sparse_matrix.c:34-90)
+ *   sort_coo_row              : device stable sort (mk_sort_coo_row)
+ *   convert_coo_to_csr        : device conversion (mk_coo_to_csr)
+ * Unlike the reference these return an error code instead of calling exit().
+ */
+#ifndef MK_HOST_SPARSE_MATRIX_H
+#define MK_HOST_SPARSE_MATRIX_H
+#include "../include/mk_krylov.h" /* SparseMatrixCOO / SparseMatrixCSR */
+
+#ifndef align_size
+#define align_size 64 /* the reference builds with -Dalign_size=64 on x86/GPU (src/Makefile_gpu) */
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+int fast_load_from_mtx_file(const char *mtx_filepath, SparseMatrixCOO *coo_matrix);
+int fast_load_from_array_file(const char *mtx_filepath, double **vals, unsigned int *count);
+int sort_coo_row(const SparseMatrixCOO *coo_matrix, SparseMatrixCOO *s_coo_matrix);
+int convert_coo_to_csr(const SparseMatrixCOO *coo_matrix, SparseMatrixCSR *csr_matrix, int free_coo);
+void free_coo(SparseMatrixCOO *m);
+void free_csr(SparseMatrixCSR *m);
+size_t get_multiple_of_align_size(size_t size);
+#ifdef __cplusplus
+}
+#endif
+#endif
