@@ -169,28 +169,36 @@ __global__ __launch_bounds__(kSortThreads) void radix_hist_kernel(const int *__r
 // Stable scatter.  Order inside a tile is (wave, item, lane): wave w owns entries
 // [w*kWaveSpan, (w+1)*kWaveSpan) of the tile and walks them 64 at a time, so the rank of
 // an entry among equal digits = (entries of that digit in earlier waves) + (in earlier
-// items of this wave) + (in lower lanes of this item).
+// items of this wave) + (in lower lanes of this item).  Entries are then regrouped by digit
+// inside LDS, so that consecutive lanes store consecutive addresses of one digit's run
+// (a direct scatter has every lane of a store instruction on a different line: 1 TB/s).
+// The LDS staging buffer is used twice: (key, col) pairs first, then the values.
 __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
     const int *__restrict__ keys_in, const int *__restrict__ cols_in, const double *__restrict__ vals_in,
     int *__restrict__ keys_out, int *__restrict__ cols_out, double *__restrict__ vals_out, int64_t n, int shift,
     unsigned mask, const uint32_t *__restrict__ table_scanned, int ntiles) {
-  __shared__ unsigned int cnt[kSortWaves][kRadix];   // running count per wave and digit
+  __shared__ unsigned int cnt[kSortWaves][kRadix];   // running count per wave and digit -> offset of the wave in the digit
   __shared__ unsigned int gbase[kRadix];             // global offset of (digit, this tile)
+  __shared__ unsigned int lstart[kRadix];            // first tile-local sorted slot of the digit
+  __shared__ __attribute__((aligned(16))) unsigned long long stage[kSortTile];   // 64 KB
   for (int i = threadIdx.x; i < kSortWaves * kRadix; i += kSortThreads) (&cnt[0][0])[i] = 0;
   for (int i = threadIdx.x; i < kRadix; i += kSortThreads) gbase[i] = table_scanned[(size_t)i * ntiles + blockIdx.x];
   __syncthreads();
 
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int64_t wbase = (int64_t)blockIdx.x * kSortTile + (int64_t)w * kWaveSpan;
+  const int64_t tbase = (int64_t)blockIdx.x * kSortTile;
+  const int64_t wbase = tbase + (int64_t)w * kWaveSpan;
+  const int tile_n = (int)min((int64_t)kSortTile, n - tbase);
   const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  unsigned int rank[kSortItems];
-  unsigned int digit[kSortItems];
+  unsigned int slot[kSortItems];    // rank among equal digits, later the tile-local sorted slot
+  int key[kSortItems];
   volatile unsigned int *mycnt = cnt[w];
 #pragma unroll
   for (int k = 0; k < kSortItems; k++) {
     const int64_t i = wbase + (int64_t)k * 64 + lane;
     const bool valid = i < n;
-    const unsigned d = valid ? (((unsigned)keys_in[i] >> shift) & mask) : 0u;
+    key[k] = valid ? keys_in[i] : 0;
+    const unsigned d = ((unsigned)key[k] >> shift) & mask;
     unsigned long long peers = __ballot(valid);
 #pragma unroll
     for (int b = 0; b < kRadixBits; b++) {
@@ -199,34 +207,70 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
     }
     const unsigned before = (unsigned)__popcll(peers & lt);
     const unsigned prev = valid ? mycnt[d] : 0u;
-    digit[k] = d;
-    rank[k] = prev + before;
+    slot[k] = prev + before;
     __builtin_amdgcn_wave_barrier();
     if (valid && before == 0) mycnt[d] = prev + (unsigned)__popcll(peers);
     __builtin_amdgcn_wave_barrier();
   }
   __syncthreads();
-  // per digit: turn the per-wave totals into exclusive offsets over waves
+  // per digit: exclusive offsets over waves, and the digit's total -> exclusive scan over digits
+  unsigned total = 0;
   if (threadIdx.x < kRadix) {
-    unsigned run = 0;
 #pragma unroll
     for (int ww = 0; ww < kSortWaves; ww++) {
       const unsigned t = cnt[ww][threadIdx.x];
-      cnt[ww][threadIdx.x] = run;
-      run += t;
+      cnt[ww][threadIdx.x] = total;
+      total += t;
     }
+    lstart[threadIdx.x] = total;
   }
   __syncthreads();
+  for (int off = 1; off < kRadix; off <<= 1) {
+    unsigned t = 0;
+    if (threadIdx.x < kRadix && threadIdx.x >= (unsigned)off) t = lstart[threadIdx.x - off];
+    __syncthreads();
+    if (threadIdx.x < kRadix) lstart[threadIdx.x] += t;
+    __syncthreads();
+  }
+  if (threadIdx.x < kRadix) lstart[threadIdx.x] -= total;   // inclusive -> exclusive
+  __syncthreads();
+  // round A: (key, col) pairs through LDS
 #pragma unroll
   for (int k = 0; k < kSortItems; k++) {
     const int64_t i = wbase + (int64_t)k * 64 + lane;
     if (i < n) {
-      const unsigned d = digit[k];
-      const size_t pos = (size_t)gbase[d] + cnt[w][d] + rank[k];
-      keys_out[pos] = keys_in[i];
-      cols_out[pos] = cols_in[i];
-      vals_out[pos] = vals_in[i];
+      const unsigned d = ((unsigned)key[k] >> shift) & mask;
+      slot[k] = lstart[d] + cnt[w][d] + slot[k];
+      stage[slot[k]] = ((unsigned long long)(unsigned)cols_in[i] << 32) | (unsigned)key[k];
     }
+  }
+  __syncthreads();
+  unsigned int gpos[kSortItems];
+#pragma unroll
+  for (int k = 0; k < kSortItems; k++) {
+    const int j = threadIdx.x + k * kSortThreads;
+    gpos[k] = 0;
+    if (j < tile_n) {
+      const unsigned long long kc = stage[j];
+      const unsigned d = ((unsigned)kc >> shift) & mask;
+      gpos[k] = gbase[d] + ((unsigned)j - lstart[d]);
+      keys_out[gpos[k]] = (int)(unsigned)kc;
+      cols_out[gpos[k]] = (int)(unsigned)(kc >> 32);
+    }
+  }
+  __syncthreads();
+  // round B: values through the same buffer
+  double *vstage = reinterpret_cast<double *>(stage);
+#pragma unroll
+  for (int k = 0; k < kSortItems; k++) {
+    const int64_t i = wbase + (int64_t)k * 64 + lane;
+    if (i < n) vstage[slot[k]] = vals_in[i];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < kSortItems; k++) {
+    const int j = threadIdx.x + k * kSortThreads;
+    if (j < tile_n) vals_out[gpos[k]] = vstage[j];
   }
 }
 
