@@ -109,7 +109,9 @@ int mk_matrix_get_info(const mk_matrix *A, mk_matrix_info *info);
 typedef enum {
   MK_SPMV_AUTO = 0,
   MK_SPMV_VECTOR = 1,      /* 2^k lanes per row, k from the mean row length (k=6: wavefront per row) */
-  MK_SPMV_STREAM = 2       /* LDS-staged nnz-balanced chunks with in-chunk row split, long rows split over blocks */
+  MK_SPMV_STREAM = 2,      /* regular rows: 256/G consecutive rows per chunk staged through LDS, one pass per row group */
+  MK_SPMV_SPLIT = 3        /* skewed rows: nnz-balanced chunks (merge-path style), products staged in LDS, rows split
+                              inside and across chunks, carries folded in a fixed order by a second small kernel */
 } mk_spmv_kernel;
 /* override the selector (lanes_per_row: 0 = keep, else 1..64 power of two) */
 int mk_matrix_set_spmv_kernel(mk_matrix *A, int kernel, int lanes_per_row);

@@ -95,8 +95,10 @@ struct mk_matrix {
   // stream kernel (fixed rows per chunk): lanes per row and LDS capacity in entries
   int stream_lanes = 0;
   int stream_cap = 0;
+  // split kernel: chunk c covers entries [c*kSplitChunk, (c+1)*kSplitChunk); chunk_row[c] = first row starting in it
   int *chunk_row = nullptr;
   int nchunks = 0;
+  double *carry = nullptr;   // 2 per chunk: partial of the row entering from the left, partial of the row leaving to the right
   // long rows (split over several blocks)
   int *long_rows = nullptr;
   int n_long = 0;
@@ -107,6 +109,7 @@ namespace mk {
 // grid-level reduction slabs: component k of block b lives at slab[k * stride + b]
 constexpr int kMaxParts = 4;
 constexpr int kSlabStride = 4096;  // >= any reduction grid we launch
+constexpr int kSplitChunk = 2048;  // entries per chunk of the split SpMV kernel
 
 int analyse_matrix(mk_matrix *A);
 int ensure_dinv(mk_matrix *A);

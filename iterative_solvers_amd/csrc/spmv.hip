@@ -90,11 +90,14 @@ int analyse_matrix(mk_matrix *A) {
   A->stream_lanes = sl;
   A->stream_cap = (int)((std::max<int64_t>(64, (int64_t)(kThreads / sl) * I.max_row_len) + 3) & ~(int64_t)3);
   const bool stream_ok = A->stream_cap <= kStreamMaxCap;
-  if (A->kernel == MK_SPMV_AUTO) A->kernel = stream_ok ? MK_SPMV_STREAM : MK_SPMV_VECTOR;
-  if (A->kernel == MK_SPMV_STREAM && !stream_ok) A->kernel = MK_SPMV_VECTOR;
+  // regular rows -> stream; rows too long for a row-aligned LDS chunk (skewed / power law) -> split
+  if (A->kernel == MK_SPMV_AUTO) A->kernel = stream_ok ? MK_SPMV_STREAM : MK_SPMV_SPLIT;
+  if (A->kernel == MK_SPMV_STREAM && !stream_ok) A->kernel = MK_SPMV_SPLIT;
+  int64_t longr = 0;
+  for (int k = 12; k < 16; k++) longr += I.hist[k];   // rows of 2048 entries or more always cross a chunk border
+  I.long_rows = longr;
   I.kernel = A->kernel;
   I.lanes_per_row = A->lanes;
-  I.long_rows = 0;
   A->analysed = true;
   return MK_OK;
 }
@@ -371,16 +374,186 @@ static int launch_stream(const mk_matrix *A, double alpha, const double *x, doub
   return fail(MK_ERR_UNSUPPORTED, "spmv: stream capacity %d too large", cap);
 }
 
+// -------------------------------------------------------------------- split kernel
+// Skewed / power-law rows.  Work is cut by ENTRIES, not rows: chunk c owns entries
+// [c*CH, (c+1)*CH), so every block streams the same number of bytes whatever the row lengths
+// (merge-path style balance).  Pass 1: coalesced 16-byte loads of val/col, gather x, products
+// into LDS.  Pass 2: the rows that START in the chunk (chunk_row[c] .. chunk_row[c+1]-1) plus
+// the row that enters from the previous chunk are reduced out of LDS, LP lanes per row with LP
+// picked per chunk from the number of rows in it.  A row that ends inside the chunk where it
+// started is written at once; pieces of rows that cross chunk borders go to carry[2c] (piece
+// of the row entering from the left) and carry[2c+1] (piece of the row leaving to the
+// right), and split_fixup_kernel folds them in chunk order: fixed order, no atomics.
+__global__ void split_chunk_rows_kernel(int64_t nrows, int64_t nnz, const int *__restrict__ rowptr, int nchunks,
+                                        int *__restrict__ chunk_row) {
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c <= nchunks; c += gridDim.x * blockDim.x) {
+    if (c == nchunks) { chunk_row[c] = (int)nrows; continue; }
+    const int64_t target = (int64_t)c * kSplitChunk;
+    int64_t lo = 0, hi = nrows;   // first row with rowptr[row] >= target
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (rowptr[mid] >= target) hi = mid; else lo = mid + 1;
+    }
+    chunk_row[c] = (int)lo;
+  }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kThreads) void spmv_split_kernel(
+    int64_t nrows, int64_t nnz, const int *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ val,
+    const int *__restrict__ chunk_row, int nchunks, const double *__restrict__ x, double *__restrict__ y, double alpha,
+    double beta, double *__restrict__ carry, double *__restrict__ slab, const int *__restrict__ done) {
+  if (done != nullptr && *done != 0) return;
+  __shared__ __attribute__((aligned(16))) double prod[kSplitChunk];
+  __shared__ double red[2 * (kThreads / 64)];
+  const int tid = threadIdx.x;
+  double acc_yx = 0.0, acc_xx = 0.0;
+  for (int c = blockIdx.x; c < nchunks; c += gridDim.x) {
+    const int64_t e0 = (int64_t)c * kSplitChunk;
+    const int64_t e1 = min(e0 + kSplitChunk, nnz);
+    // pass 1
+#pragma unroll
+    for (int i = 0; i < kSplitChunk / (2 * kThreads); i++) {
+      const int64_t k = e0 + (int64_t)(tid + i * kThreads) * 2;
+      double p0 = 0.0, p1 = 0.0;
+      if (k < e1) {
+        const double2 v = *reinterpret_cast<const double2 *>(val + k);
+        const int2 cc = *reinterpret_cast<const int2 *>(col + k);
+        p0 = v.x * x[cc.x];
+        if (k + 1 < e1) p1 = v.y * x[cc.y];
+      }
+      *reinterpret_cast<double2 *>(prod + (k - e0)) = make_double2(p0, p1);
+    }
+    __syncthreads();
+    // pass 2
+    const int rs = chunk_row[c], re = chunk_row[c + 1];          // rows that start in this chunk
+    const bool has_in = (rs > 0) && (rs == (int)nrows || (int64_t)rowptr[rs] > e0) && e0 < e1;   // a row enters from the left
+    const int m = (re - rs) + 1;                                  // slot 0 = entering row
+    int lp = 1;
+    while (lp < 64 && lp * 2 * m <= kThreads) lp *= 2;
+    const int groups = kThreads / lp;
+    const int g = tid % lp;
+    for (int q = tid / lp; q < m; q += groups) {
+      const bool entering = (q == 0);
+      const int r = entering ? rs - 1 : rs + q - 1;
+      double sum = 0.0;
+      int64_t sb = 0, se = 0, t_r = 0;
+      if (!entering || has_in) {
+        t_r = rowptr[r + 1];
+        sb = entering ? e0 : (int64_t)rowptr[r];
+        se = min(t_r, e1);
+        for (int64_t j = sb + g; j < se; j += lp) sum += prod[j - e0];
+      }
+      for (int off = lp >> 1; off > 0; off >>= 1) sum += __shfl_down(sum, off, lp);
+      if (g == 0 && (!entering || has_in)) {
+        if (entering) {
+          carry[2 * c] = sum;                                     // folded by the fix-up kernel
+        } else if (t_r <= e1) {                                   // starts and ends here: final
+          if (MODE == 0) {
+            y[r] = (beta == 0.0) ? alpha * sum : alpha * sum + beta * y[r];
+          } else {
+            y[r] = sum;
+            const double xr = x[r];
+            acc_yx += sum * xr;
+            acc_xx += xr * xr;
+          }
+        } else {
+          carry[2 * c + 1] = sum;                                 // leaves to the right
+          if (MODE == 1) { const double xr = x[r]; acc_xx += xr * xr; }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (MODE == 1) {
+    double v[2] = {acc_yx, acc_xx};
+    block_sum<2, kThreads>(v, red);
+    if (threadIdx.x == 0) {
+      slab[0 * kSlabStride + blockIdx.x] = v[0];
+      slab[1 * kSlabStride + blockIdx.x] = v[1];
+    }
+  }
+}
+
+// one thread per chunk whose last starting row runs past the chunk's end: add the pieces
+template <int MODE>
+__global__ __launch_bounds__(kThreads) void split_fixup_kernel(
+    int64_t nrows, int64_t nnz, const int *__restrict__ rowptr, const int *__restrict__ chunk_row, int nchunks,
+    const double *__restrict__ x, double *__restrict__ y, double alpha, double beta, const double *__restrict__ carry,
+    double *__restrict__ slab, const int *__restrict__ done) {
+  if (done != nullptr && *done != 0) return;
+  __shared__ double red[2 * (kThreads / 64)];
+  double acc_yx = 0.0;
+  for (int c = blockIdx.x * kThreads + threadIdx.x; c < nchunks; c += gridDim.x * kThreads) {
+    const int rs = chunk_row[c], re = chunk_row[c + 1];
+    if (re <= rs) continue;                                       // no row starts here
+    const int r = re - 1;
+    const int64_t t_r = rowptr[r + 1];
+    const int64_t e1 = min(((int64_t)c + 1) * kSplitChunk, nnz);
+    if (t_r <= e1) continue;                                      // ends inside its own chunk
+    double total = carry[2 * c + 1];
+    for (int d = c + 1; d < nchunks; d++) {
+      total += carry[2 * d];
+      if (t_r <= ((int64_t)d + 1) * kSplitChunk) break;
+    }
+    if (MODE == 0) {
+      y[r] = (beta == 0.0) ? alpha * total : alpha * total + beta * y[r];
+    } else {
+      y[r] = total;
+      acc_yx += total * x[r];
+    }
+  }
+  if (MODE == 1) {
+    double v[2] = {acc_yx, 0.0};
+    block_sum<2, kThreads>(v, red);
+    if (threadIdx.x == 0) {
+      slab[0 * kSlabStride + blockIdx.x] = v[0];
+      slab[1 * kSlabStride + blockIdx.x] = v[1];
+    }
+  }
+}
+
+static int prepare_split(mk_matrix *A) {
+  if (A->chunk_row) return MK_OK;
+  Context &c = ctx();
+  A->nchunks = (int)((A->nnz + kSplitChunk - 1) / kSplitChunk);
+  if (A->nchunks < 1) A->nchunks = 1;   // a matrix without entries still has rows to write
+  MK_TRY(dev_alloc(&A->chunk_row, (size_t)A->nchunks + 1));
+  MK_TRY(dev_alloc(&A->carry, (size_t)2 * A->nchunks));
+  const int blocks = std::min((A->nchunks + 1 + 255) / 256, 1024);
+  hipLaunchKernelGGL(split_chunk_rows_kernel, dim3(blocks), dim3(256), 0, c.stream, A->nrows, A->nnz, A->rowptr, A->nchunks, A->chunk_row);
+  MK_HIP(hipGetLastError());
+  return MK_OK;
+}
+
+template <int MODE>
+static int launch_split(const mk_matrix *A, double alpha, const double *x, double beta, double *y, double *slab,
+                        const int *done, int *nblocks) {
+  Context &c = ctx();
+  MK_TRY(prepare_split(const_cast<mk_matrix *>(A)));
+  const int main_blocks = std::max(1, std::min(A->nchunks, c.num_cus * 8));
+  const int fix_blocks = std::max(1, std::min((A->nchunks + kThreads - 1) / kThreads, 1024));
+  if (nblocks) *nblocks = main_blocks + fix_blocks;
+  hipLaunchKernelGGL((spmv_split_kernel<MODE>), dim3(main_blocks), dim3(kThreads), 0, c.stream, A->nrows, A->nnz, A->rowptr, A->col,
+                     A->val, A->chunk_row, A->nchunks, x, y, alpha, beta, A->carry, slab, done);
+  hipLaunchKernelGGL((split_fixup_kernel<MODE>), dim3(fix_blocks), dim3(kThreads), 0, c.stream, A->nrows, A->nnz, A->rowptr,
+                     A->chunk_row, A->nchunks, x, y, alpha, beta, A->carry, slab ? slab + main_blocks : nullptr, done);
+  MK_HIP(hipGetLastError());
+  return MK_OK;
+}
+
 int launch_spmv(const mk_matrix *A, double alpha, const double *x, double beta, double *y) {
   MK_TRY(analyse_matrix(const_cast<mk_matrix *>(A)));
   if (A->nrows == 0) return MK_OK;
   if (A->kernel == MK_SPMV_STREAM) return launch_stream<0>(A, alpha, x, beta, y, nullptr, nullptr, nullptr);
+  if (A->kernel == MK_SPMV_SPLIT) return launch_split<0>(A, alpha, x, beta, y, nullptr, nullptr, nullptr);
   return launch_vector<0>(A, alpha, x, beta, y, nullptr, nullptr, nullptr);
 }
 
 int launch_spmv_dot(const mk_matrix *A, const double *x, double *y, double *slab, const int *done, int *nblocks) {
   MK_TRY(analyse_matrix(const_cast<mk_matrix *>(A)));
   if (A->kernel == MK_SPMV_STREAM) return launch_stream<1>(A, 1.0, x, 0.0, y, slab, done, nblocks);
+  if (A->kernel == MK_SPMV_SPLIT) return launch_split<1>(A, 1.0, x, 0.0, y, slab, done, nblocks);
   return launch_vector<1>(A, 1.0, x, 0.0, y, slab, done, nblocks);
 }
 
@@ -438,7 +611,7 @@ int mk_matrix_set_spmv_kernel(mk_matrix *A, int kernel, int lanes_per_row) {
   MK_REQUIRE_INIT();
   if (!A) return fail(MK_ERR_INVALID, "mk_matrix_set_spmv_kernel: null matrix");
   MK_TRY(analyse_matrix(A));
-  if (kernel != MK_SPMV_AUTO && kernel != MK_SPMV_VECTOR && kernel != MK_SPMV_STREAM)
+  if (kernel != MK_SPMV_AUTO && kernel != MK_SPMV_VECTOR && kernel != MK_SPMV_STREAM && kernel != MK_SPMV_SPLIT)
     return fail(MK_ERR_INVALID, "mk_matrix_set_spmv_kernel: unknown kernel %d", kernel);
   if (lanes_per_row != 0) {
     if (lanes_per_row < 1 || lanes_per_row > 64 || (lanes_per_row & (lanes_per_row - 1)))

@@ -192,6 +192,52 @@ def test_spmv_skewed_rows_rmat():
     _check_spmv(A, rp, ci, val, n, n, np.random.default_rng(5))
 
 
+@pytest.mark.parametrize("case", ["one_huge_row", "many_long_rows", "long_then_empty_tail", "no_entries", "dense_block"])
+def test_spmv_split_kernel_row_splitting(case):
+    """rows that cross one or many 2048-entry chunk borders, empty rows around them"""
+    rng = np.random.default_rng(len(case))
+    if case == "one_huge_row":
+        n, lens = 50, np.zeros(50, np.int64)
+        lens[7] = 10000; lens[8] = 3; lens[49] = 1
+    elif case == "many_long_rows":
+        n = 400
+        lens = rng.integers(0, 30, n)
+        lens[rng.integers(0, n, 12)] = rng.integers(1500, 9000, 12)
+    elif case == "long_then_empty_tail":
+        n, lens = 3000, np.zeros(3000, np.int64)
+        lens[0] = 2048; lens[1] = 2048 * 3; lens[2] = 1; lens[10] = 4095
+    elif case == "no_entries":
+        n, lens = 100, np.zeros(100, np.int64)
+    else:
+        n, lens = 64, np.full(64, 512)
+    ncols = 5000
+    rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    ci = rng.integers(0, ncols, rp[-1]).astype(np.int32)
+    v = rng.normal(size=rp[-1])
+    A = mk.Matrix.from_csr(n, ncols, rp, ci, v)
+    A.set_spmv_kernel(mk.SPMV_SPLIT)
+    _check_spmv(A, rp, ci, v, n, ncols, rng)
+    _check_spmv(A, rp, ci, v, n, ncols, rng, alpha=-2.0, beta=0.5)
+    if case == "one_huge_row":
+        assert A.info().long_rows == 1
+
+
+def test_spmv_split_fused_dot_square():
+    scale, ne = 13, 1 << 18
+    r, c, v = oracle.rmat_coo(scale, ne, seed=3)
+    n = 1 << scale
+    rp, ci, val = oracle.coo_to_csr(n, r, c, v)
+    A = mk.Matrix.from_csr(n, n, rp, ci, val)
+    assert A.info().kernel == mk.SPMV_SPLIT                   # skewed rows -> nnz-balanced kernel
+    xh = np.random.default_rng(1).normal(size=n)
+    x, y = mk.Vector(n, values=xh), mk.Vector(n)
+    ytx, xtx = A.spmv_dot(x, y)
+    ref = oracle.csr_spmv(rp, ci, val, xh)
+    mag = oracle.csr_spmv(rp, ci, np.abs(val), np.abs(xh))
+    assert (np.abs(y.get() - ref) / np.maximum(mag, 1e-300)).max() <= SPMV_RTOL
+    assert abs(ytx - ref @ xh) <= 1e-12 * (mag @ np.abs(xh)) and abs(xtx - xh @ xh) <= 1e-13 * (xh @ xh)
+
+
 def test_spmv_dot_fused():
     rp, ci, v = oracle.stencil_csr(7, 20, 21, 22)
     n = rp.size - 1
