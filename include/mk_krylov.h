@@ -102,7 +102,9 @@ typedef struct {
   int64_t hist[16];        /* row-length histogram: bucket k holds rows with len in [2^(k-1), 2^k), bucket 0 = empty rows */
   int32_t kernel;          /* mk_spmv_kernel chosen from the histogram */
   int32_t lanes_per_row;   /* for the vector kernels */
-  int64_t long_rows;       /* rows routed to the long-row path */
+  int64_t long_rows;       /* rows of >= 2048 entries (always split over chunks by MK_SPMV_SPLIT) */
+  int64_t index_patterns;  /* > 0: column indices are served from a table of that many (column - row) patterns
+                              (lossless; the stream kernel then reads 2 B per row instead of 4 B per entry) */
 } mk_matrix_info;
 int mk_matrix_get_info(const mk_matrix *A, mk_matrix_info *info);
 

@@ -95,6 +95,12 @@ struct mk_matrix {
   // stream kernel (fixed rows per chunk): lanes per row and LDS capacity in entries
   int stream_lanes = 0;
   int stream_cap = 0;
+  // column-index compression for the stream kernel: rows that share the same list of
+  // (column - row) offsets share one table entry; the kernel then reads 2 B per row instead
+  // of 4 B per entry.  pat == nullptr -> not compressed.
+  unsigned short *pat = nullptr;   // pattern id per row
+  int *ptab = nullptr;             // npat x (pml+1) ints: length, offsets
+  int npat = 0, pml = 0;
   // split kernel: chunk c covers entries [c*kSplitChunk, (c+1)*kSplitChunk); chunk_row[c] = first row starting in it
   int *chunk_row = nullptr;
   int nchunks = 0;

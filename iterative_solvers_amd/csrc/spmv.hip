@@ -57,6 +57,130 @@ __global__ void diag_inverse_kernel(int64_t nrows, const int *__restrict__ rowpt
   }
 }
 
+// --------------------------------------------------------- column-index compression
+// Lossless: the product reads exactly the same (column, value) pairs in the same order.
+constexpr int kPatSlots = 1 << 16;
+constexpr int kPatMaxLen = 32;      // rows longer than this are not worth a table entry
+constexpr int kPatMaxInts = 8192;   // table must fit 32 KB of LDS beside the value stage
+
+__device__ __forceinline__ unsigned long long pat_hash(int64_t row, const int *__restrict__ rowptr, const int *__restrict__ col) {
+  unsigned long long h = 0xCBF29CE484222325ULL;
+  const int b = rowptr[row], e = rowptr[row + 1];
+  h = (h ^ (unsigned long long)(unsigned)(e - b)) * 0x100000001B3ULL;
+  for (int k = b; k < e; k++) h = (h ^ (unsigned long long)(unsigned)(col[k] - (int)row)) * 0x100000001B3ULL;
+  h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ULL; h ^= h >> 32;
+  return h | 1ULL;   // 0 marks an empty slot
+}
+
+__global__ void pat_insert_kernel(int64_t nrows, const int *__restrict__ rowptr, const int *__restrict__ col,
+                                  unsigned long long *__restrict__ keys, int *__restrict__ slot_of_row, int *__restrict__ fail) {
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += (int64_t)gridDim.x * blockDim.x) {
+    const unsigned long long h = pat_hash(r, rowptr, col);
+    unsigned s = (unsigned)(h >> 40) & (kPatSlots - 1);
+    int probes = 0;
+    for (; probes < kPatSlots; probes++) {
+      const unsigned long long old = atomicCAS(&keys[s], 0ULL, h);
+      if (old == 0ULL || old == h) break;
+      s = (s + 1) & (kPatSlots - 1);
+    }
+    if (probes == kPatSlots) *fail = 1;
+    slot_of_row[r] = (int)s;
+  }
+}
+
+// dense ids in slot order (deterministic whatever the insertion order was); one block
+__global__ __launch_bounds__(1024) void pat_compact_kernel(const unsigned long long *__restrict__ keys, int *__restrict__ id_of_slot,
+                                                           int *__restrict__ npat) {
+  __shared__ int sums[1024];
+  constexpr int PER = kPatSlots / 1024;
+  const int base = threadIdx.x * PER;
+  int cnt = 0;
+  for (int i = 0; i < PER; i++) cnt += keys[base + i] != 0ULL;
+  sums[threadIdx.x] = cnt;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    int t = (threadIdx.x >= (unsigned)off) ? sums[threadIdx.x - off] : 0;
+    __syncthreads();
+    sums[threadIdx.x] += t;
+    __syncthreads();
+  }
+  int run = sums[threadIdx.x] - cnt;
+  for (int i = 0; i < PER; i++) {
+    id_of_slot[base + i] = run;
+    run += keys[base + i] != 0ULL;
+  }
+  if (threadIdx.x == 1023) *npat = sums[1023];
+}
+
+__global__ void pat_assign_kernel(int64_t nrows, const int *__restrict__ rowptr, const int *__restrict__ col,
+                                  const int *__restrict__ slot_of_row, const int *__restrict__ id_of_slot,
+                                  unsigned short *__restrict__ pat, int *__restrict__ ptab, int pml, int *__restrict__ written) {
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += (int64_t)gridDim.x * blockDim.x) {
+    const int id = id_of_slot[slot_of_row[r]];
+    pat[r] = (unsigned short)id;
+    if (atomicExch(&written[id], 1) == 0) {
+      const int b = rowptr[r], e = rowptr[r + 1];
+      int *t = ptab + (size_t)id * (pml + 1);
+      t[0] = e - b;
+      for (int k = b; k < e; k++) t[1 + k - b] = col[k] - (int)r;
+      for (int k = e - b; k < pml; k++) t[1 + k] = 0;
+    }
+  }
+}
+
+// hash collisions would silently change the matrix: compare every row with its table entry
+__global__ void pat_verify_kernel(int64_t nrows, const int *__restrict__ rowptr, const int *__restrict__ col,
+                                  const unsigned short *__restrict__ pat, const int *__restrict__ ptab, int pml, int *__restrict__ fail) {
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += (int64_t)gridDim.x * blockDim.x) {
+    const int *t = ptab + (size_t)pat[r] * (pml + 1);
+    const int b = rowptr[r], e = rowptr[r + 1];
+    bool ok = (t[0] == e - b);
+    for (int k = b; ok && k < e; k++) ok = (t[1 + k - b] == col[k] - (int)r);
+    if (!ok) *fail = 1;
+  }
+}
+
+static int try_compress_indices(mk_matrix *A) {
+  static const int disabled = getenv("MK_NO_INDEX_COMPRESSION") ? atoi(getenv("MK_NO_INDEX_COMPRESSION")) : 0;
+  if (disabled || A->pat || A->nrows == 0 || A->info.max_row_len > kPatMaxLen || A->info.max_row_len < 1) return MK_OK;
+  Context &c = ctx();
+  const int pml = A->info.max_row_len;
+  unsigned long long *keys = nullptr;
+  int *slot = nullptr, *ids = nullptr, *flags = nullptr, *written = nullptr;   // flags: [0] fail, [1] npat
+  MK_TRY(dev_alloc(&keys, (size_t)kPatSlots));
+  MK_TRY(dev_alloc(&slot, (size_t)A->nrows));
+  MK_TRY(dev_alloc(&ids, (size_t)kPatSlots));
+  MK_TRY(dev_alloc(&flags, 2));
+  MK_HIP(hipMemsetAsync(keys, 0, sizeof(unsigned long long) * kPatSlots, c.stream));
+  MK_HIP(hipMemsetAsync(flags, 0, sizeof(int) * 2, c.stream));
+  const int blocks = (int)std::min<int64_t>((A->nrows + 255) / 256, 4096);
+  hipLaunchKernelGGL(pat_insert_kernel, dim3(blocks), dim3(256), 0, c.stream, A->nrows, A->rowptr, A->col, keys, slot, flags);
+  hipLaunchKernelGGL(pat_compact_kernel, dim3(1), dim3(1024), 0, c.stream, keys, ids, flags + 1);
+  int h[2] = {0, 0};
+  MK_HIP(hipMemcpyAsync(h, flags, sizeof(h), hipMemcpyDeviceToHost, c.stream));
+  MK_HIP(hipStreamSynchronize(c.stream));
+  bool ok = (h[0] == 0) && h[1] >= 1 && h[1] <= 65535 && (int64_t)h[1] * (pml + 1) <= kPatMaxInts;
+  if (ok) {
+    const int npat = h[1];
+    MK_TRY(dev_alloc(&A->pat, (size_t)A->nrows));
+    MK_TRY(dev_alloc(&A->ptab, (size_t)npat * (pml + 1)));
+    MK_TRY(dev_alloc(&written, (size_t)npat));
+    MK_HIP(hipMemsetAsync(written, 0, sizeof(int) * npat, c.stream));
+    hipLaunchKernelGGL(pat_assign_kernel, dim3(blocks), dim3(256), 0, c.stream, A->nrows, A->rowptr, A->col, slot, ids, A->pat, A->ptab, pml, written);
+    hipLaunchKernelGGL(pat_verify_kernel, dim3(blocks), dim3(256), 0, c.stream, A->nrows, A->rowptr, A->col, A->pat, A->ptab, pml, flags);
+    MK_HIP(hipMemcpyAsync(h, flags, sizeof(int), hipMemcpyDeviceToHost, c.stream));
+    MK_HIP(hipStreamSynchronize(c.stream));
+    if (h[0] != 0) {   // collision: keep the plain CSR path
+      dev_free(A->pat); dev_free(A->ptab);
+      A->pat = nullptr; A->ptab = nullptr;
+    } else {
+      A->npat = npat; A->pml = pml;
+    }
+  }
+  dev_free(keys); dev_free(slot); dev_free(ids); dev_free(flags); dev_free(written);
+  return MK_OK;
+}
+
 int analyse_matrix(mk_matrix *A) {
   if (A->analysed) return MK_OK;
   Context &c = ctx();
@@ -98,6 +222,9 @@ int analyse_matrix(mk_matrix *A) {
   I.long_rows = longr;
   I.kernel = A->kernel;
   I.lanes_per_row = A->lanes;
+  I.index_patterns = 0;
+  if (A->kernel == MK_SPMV_STREAM) MK_TRY(try_compress_indices(A));
+  I.index_patterns = A->pat ? A->npat : 0;
   A->analysed = true;
   return MK_OK;
 }
@@ -203,17 +330,21 @@ typedef int i4_t __attribute__((ext_vector_type(4)));
 // the x gathers of chunk k and their first use, so they stay in flight through pass 2 and
 // the barrier (loads retire in order: anything issued BEFORE the gathers would be waited
 // for with them).
-template <int G, int MODE, int U>
+// COMP: column indices come from the pattern table (pat/ptab, staged in LDS) instead of col[].
+template <int G, int MODE, int U, bool COMP>
 __global__ __launch_bounds__(kThreads) void spmv_stream_kernel(
     int64_t nrows, const int *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ val,
     const double *__restrict__ x, double *__restrict__ y, double alpha, double beta, double *__restrict__ slab,
-    const int *__restrict__ done, int cap) {
+    const int *__restrict__ done, int cap, const unsigned short *__restrict__ pat, const int *__restrict__ ptab,
+    int tab_ints, int pml) {
   if (done != nullptr && *done != 0) return;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   double *sval = reinterpret_cast<double *>(smem_raw);                     // cap + 2 doubles
-  int *scol = reinterpret_cast<int *>(smem_raw + (size_t)(cap + 2) * 8);   // cap + 8 ints
+  int *scol = reinterpret_cast<int *>(smem_raw + (size_t)(cap + 2) * 8);   // cap + 8 ints, or the pattern table
   constexpr int R = kThreads / G;
-  constexpr int NV = 2 * U, NI = U;
+  constexpr int NV = 2 * U, NI = COMP ? 0 : U;
+  if (COMP)
+    for (int i = threadIdx.x; i < tab_ints; i += kThreads) scol[i] = ptab[i];   // visible after the first barrier below
   const int tid = threadIdx.x;
   const int g = tid % G, rl = tid / G;
   const int64_t nchunks = (nrows + R - 1) / R;
@@ -223,7 +354,7 @@ __global__ __launch_bounds__(kThreads) void spmv_stream_kernel(
   double acc_yx = 0.0, acc_xx = 0.0;
 
   d2_t rv[NV];
-  i4_t ri[NI];
+  i4_t ri[NI > 0 ? NI : 1];
   int64_t chunk = first + slot;
   int cb = 0, ce = 0;
   int64_t r0 = 0, r1 = 0;
@@ -239,6 +370,7 @@ __global__ __launch_bounds__(kThreads) void spmv_stream_kernel(
       const int k = ib_ + (tid + i * kThreads) * 4;
       if (k < ce_) ri[i] = *reinterpret_cast<const i4_t *>(col + k);
     }
+    (void)ib_;
   };
   if (chunk < last) {
     r0 = chunk * R;
@@ -261,11 +393,13 @@ __global__ __launch_bounds__(kThreads) void spmv_stream_kernel(
     }
     const int64_t row = r0 + rl;
     const bool have_row = row < r1;
-    int b = 0, e = 0;
+    int b = 0, e = 0, pid = 0;
     if (have_row) { b = rowptr[row] - cb; e = rowptr[row + 1] - cb; }
+    if (COMP && have_row) pid = pat[row];
     __syncthreads();
     const double *sv = sval + (cb - vb);
-    const int *sc = scol + (cb - ib);
+    const int *sc = COMP ? scol + pid * (pml + 1) + 1 - b : scol + (cb - ib);   // sc[j]: column (or column - row) of entry j
+    const int cadd = COMP ? (int)row : 0;
     // first 8 entries of the row (per lane): all gathers issued before anything waits
     const int lastj = max(e - 1, 0);
     int cj[8];
@@ -274,7 +408,7 @@ __global__ __launch_bounds__(kThreads) void spmv_stream_kernel(
 #pragma unroll
     for (int t = 0; t < 8; t++) {
       const int j = min(b + g + t * G, lastj);
-      cj[t] = any ? sc[j] : 0;
+      cj[t] = any ? sc[j] + cadd : 0;
       vj[t] = any ? sv[j] : 0.0;
     }
 #pragma unroll
@@ -296,7 +430,7 @@ __global__ __launch_bounds__(kThreads) void spmv_stream_kernel(
 #pragma unroll
     for (int t = 0; t < 8; t++)
       if (have_row && b + g + t * G < e) sum += vj[t] * xj[t];
-    for (int j = b + g + 8 * G; j < e; j += G) sum += sv[j] * x[sc[j]];   // rows longer than 8 lanes' worth
+    for (int j = b + g + 8 * G; j < e; j += G) sum += sv[j] * x[sc[j] + cadd];   // rows longer than 8 lanes' worth
     if (G > 1) sum = group_sum<G>(sum);
     if (g == 0 && have_row) {
       if (MODE == 0) {
@@ -321,12 +455,13 @@ __global__ __launch_bounds__(kThreads) void spmv_stream_kernel(
   }
 }
 
-template <int MODE, int U>
+template <int MODE, int U, bool COMP>
 static int launch_stream_u(const mk_matrix *A, double alpha, const double *x, double beta, double *y, double *slab,
                            const int *done, int *nblocks) {
   Context &c = ctx();
   const int G = A->stream_lanes, cap = A->stream_cap;
-  const size_t lds = (size_t)(cap + 2) * 8 + (size_t)(cap + 8) * 4;  // cap is a multiple of 4
+  const int tab_ints = COMP ? A->npat * (A->pml + 1) : 0;
+  const size_t lds = (size_t)(cap + 2) * 8 + (COMP ? (size_t)tab_ints * 4 + 16 : (size_t)(cap + 8) * 4);  // cap is a multiple of 4
   const int64_t nchunks = (A->nrows + (kThreads / G) - 1) / (kThreads / G);
   // resident blocks per CU for this instantiation (registers + LDS), so the grid is one full wave of blocks
   static const int env_bpc = getenv("MK_STREAM_BPC") ? atoi(getenv("MK_STREAM_BPC")) : 0;
@@ -334,7 +469,7 @@ static int launch_stream_u(const mk_matrix *A, double alpha, const double *x, do
   if (per_cu <= 0) {
     int occ = 0;
     hipError_t oe = hipErrorInvalidValue;
-#define MK_OCC_S(GG) case GG: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, spmv_stream_kernel<GG, MODE, U>, kThreads, lds); break;
+#define MK_OCC_S(GG) case GG: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, spmv_stream_kernel<GG, MODE, U, COMP>, kThreads, lds); break;
     switch (G) { MK_OCC_S(1) MK_OCC_S(2) MK_OCC_S(4) MK_OCC_S(8) MK_OCC_S(16) MK_OCC_S(32) MK_OCC_S(64) default: break; }
 #undef MK_OCC_S
     per_cu = (oe == hipSuccess && occ > 0) ? std::min(occ, 8) : 4;
@@ -345,8 +480,9 @@ static int launch_stream_u(const mk_matrix *A, double alpha, const double *x, do
   if (nblocks) *nblocks = (int)blocks;
 #define MK_LAUNCH_S(GG)                                                                                            \
   case GG:                                                                                                         \
-    hipLaunchKernelGGL((spmv_stream_kernel<GG, MODE, U>), dim3((unsigned)blocks), dim3(kThreads), lds, c.stream,  \
-                       A->nrows, A->rowptr, A->col, A->val, x, y, alpha, beta, slab, done, cap);                   \
+    hipLaunchKernelGGL((spmv_stream_kernel<GG, MODE, U, COMP>), dim3((unsigned)blocks), dim3(kThreads), lds,      \
+                       c.stream, A->nrows, A->rowptr, A->col, A->val, x, y, alpha, beta, slab, done, cap, A->pat,  \
+                       A->ptab, tab_ints, A->pml);                                                                 \
     break;
   switch (G) {
     MK_LAUNCH_S(1)
@@ -368,9 +504,15 @@ template <int MODE>
 static int launch_stream(const mk_matrix *A, double alpha, const double *x, double beta, double *y, double *slab,
                          const int *done, int *nblocks) {
   const int cap = A->stream_cap;
-  if (cap <= 1024 * 1 - 8) return launch_stream_u<MODE, 1>(A, alpha, x, beta, y, slab, done, nblocks);
-  if (cap <= 1024 * 2 - 8) return launch_stream_u<MODE, 2>(A, alpha, x, beta, y, slab, done, nblocks);
-  if (cap <= 1024 * 3 - 8) return launch_stream_u<MODE, 3>(A, alpha, x, beta, y, slab, done, nblocks);
+  if (A->pat) {
+    if (cap <= 1024 * 1 - 8) return launch_stream_u<MODE, 1, true>(A, alpha, x, beta, y, slab, done, nblocks);
+    if (cap <= 1024 * 2 - 8) return launch_stream_u<MODE, 2, true>(A, alpha, x, beta, y, slab, done, nblocks);
+    if (cap <= 1024 * 3 - 8) return launch_stream_u<MODE, 3, true>(A, alpha, x, beta, y, slab, done, nblocks);
+  } else {
+    if (cap <= 1024 * 1 - 8) return launch_stream_u<MODE, 1, false>(A, alpha, x, beta, y, slab, done, nblocks);
+    if (cap <= 1024 * 2 - 8) return launch_stream_u<MODE, 2, false>(A, alpha, x, beta, y, slab, done, nblocks);
+    if (cap <= 1024 * 3 - 8) return launch_stream_u<MODE, 3, false>(A, alpha, x, beta, y, slab, done, nblocks);
+  }
   return fail(MK_ERR_UNSUPPORTED, "spmv: stream capacity %d too large", cap);
 }
 

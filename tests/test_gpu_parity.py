@@ -145,6 +145,7 @@ def test_spmv_stream_kernel_stencils(kind, dims):
     n = rp.size - 1
     A = mk.Matrix.from_csr(n, n, rp, ci, v)
     assert A.info().kernel == mk.SPMV_STREAM          # regular rows -> LDS-staged kernel
+    assert 1 <= A.info().index_patterns <= 27         # stencil rows share a few (column - row) patterns
     _check_spmv(A, rp, ci, v, n, n, rng)
     _check_spmv(A, rp, ci, v, n, n, rng, alpha=-1.0, beta=1.0)
     if kind != 27:
@@ -155,6 +156,39 @@ def test_spmv_stream_kernel_stencils(kind, dims):
         assert np.array_equal(y.get(), oracle.csr_spmv(rp, ci, v, xh))
     A.set_spmv_kernel(mk.SPMV_VECTOR)
     _check_spmv(A, rp, ci, v, n, n, rng)
+
+
+def test_spmv_index_compression_is_lossless_and_optional():
+    """random short rows have ~n distinct patterns: the table would not fit, so the plain stream
+    kernel runs; a block-structured matrix with a few hundred patterns is compressed; both must
+    agree bit for bit with the uncompressed product (same pairs, same order)"""
+    rng = np.random.default_rng(4)
+    n = 6000
+    lens = rng.integers(1, 9, n)
+    rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    ci = rng.integers(0, n, rp[-1]).astype(np.int32)
+    v = rng.normal(size=rp[-1])
+    A = mk.Matrix.from_csr(n, n, rp, ci, v)
+    assert A.info().kernel == mk.SPMV_STREAM and A.info().index_patterns == 0
+    _check_spmv(A, rp, ci, v, n, n, rng)
+    # 300 patterns: row i uses offsets of pattern i % 300 (wrapped into range)
+    pats = [np.sort(rng.choice(np.arange(-40, 41), size=int(rng.integers(1, 9)), replace=False)) for _ in range(300)]
+    rows_c, lens2 = [], []
+    for i in range(n):
+        c = i + pats[i % 300]
+        c = c[(c >= 0) & (c < n)]
+        rows_c.append(c)
+        lens2.append(c.size)
+    rp2 = np.concatenate([[0], np.cumsum(lens2)]).astype(np.int32)
+    ci2 = np.concatenate(rows_c).astype(np.int32)
+    v2 = rng.normal(size=rp2[-1])
+    B = mk.Matrix.from_csr(n, n, rp2, ci2, v2)
+    assert 300 <= B.info().index_patterns < 1200
+    xh = rng.normal(size=n)
+    x, y = mk.Vector(n, values=xh), mk.Vector(n)
+    B.spmv(x, y)
+    assert np.array_equal(y.get(), oracle.csr_spmv(rp2, ci2, v2, xh))    # one lane per row: reference order
+    _check_spmv(B, rp2, ci2, v2, n, n, rng, alpha=0.7, beta=-1.3)
 
 
 def test_spmv_stream_ragged_rows():

@@ -23,5 +23,5 @@ for _ in range(reps):
 ms = mk.timer_stop() / reps
 b = 12 * A.nnz + 20 * n + 4
 i = A.info()
-print(f"kind={kind} {nx}x{ny}x{nz} kernel={i.kernel} lanes={i.lanes_per_row} spmv+dot {ms*1e3:.1f} us  "
+print(f"kind={kind} {nx}x{ny}x{nz} kernel={i.kernel} patterns={i.index_patterns} spmv+dot {ms*1e3:.1f} us  "
       f"{b/ms/1e6:.1f} GB/s  ({b/ms/1e6/8000:.3f} of 8 TB/s)")
