@@ -137,3 +137,35 @@ int convert_coo_to_csr(const SparseMatrixCOO *coo, SparseMatrixCSR *csr, int fre
   }
   return rc;
 }
+
+/* Synthetic test input: write a 5/7/27-point stencil as a general real coordinate file, rows
+ * ascending, columns ascending inside a row (BASELINE config 1 feeds the solver through the
+ * .mtx path).  No reference counterpart. */
+int write_stencil_mtx(const char *path, int kind, int nx, int ny, int nz) {
+  if (kind == 5) nz = 1;
+  FILE *f = fopen(path, "w");
+  if (!f) return 1;
+  const long long n = (long long)nx * ny * nz;
+  long long nnz = 0;
+  for (int pass = 0; pass < 2; pass++) {
+    if (pass == 1) fprintf(f, "%%%%MatrixMarket matrix coordinate real general\n%lld %lld %lld\n", n, n, nnz);
+    for (long long row = 0; row < n; row++) {
+      const int ix = (int)(row % nx), iy = (int)((row / nx) % ny), iz = (int)(row / ((long long)nx * ny));
+      for (int dz = -1; dz <= 1; dz++)
+        for (int dy = -1; dy <= 1; dy++)
+          for (int dx = -1; dx <= 1; dx++) {
+            const int man = (dx != 0) + (dy != 0) + (dz != 0);
+            if (kind != 27 && man > 1) continue;
+            if (kind == 5 && dz != 0) continue;
+            const int x = ix + dx, y = iy + dy, z = iz + dz;
+            if (x < 0 || x >= nx || y < 0 || y >= ny || z < 0 || z >= nz) continue;
+            if (pass == 0) { nnz++; continue; }
+            const long long c = ((long long)z * ny + y) * nx + x;
+            const double diag = kind == 27 ? 26.0 : kind == 7 ? 6.0 : 4.0;
+            fprintf(f, "%lld %lld %g\n", row + 1, c + 1, man == 0 ? diag : -1.0);
+          }
+    }
+  }
+  fclose(f);
+  return 0;
+}

@@ -25,6 +25,7 @@ int convert_coo_to_csr(const SparseMatrixCOO *coo_matrix, SparseMatrixCSR *csr_m
 void free_coo(SparseMatrixCOO *m);
 void free_csr(SparseMatrixCSR *m);
 size_t get_multiple_of_align_size(size_t size);
+int write_stencil_mtx(const char *path, int kind, int nx, int ny, int nz);   /* synthetic test input */
 #ifdef __cplusplus
 }
 #endif

@@ -206,6 +206,8 @@ int mk_dist_spmv(int nranks_here, mk_dist_matrix **A, mk_vector **x, mk_vector *
 /* HYPRE_ParCSRPCGSetup + HYPRE_ParCSRPCGSolve (solvers.c:747-754) on the distributed operator;
  * settings and results through the mk_pcg_set_* / mk_pcg_get_* calls above */
 int mk_dist_pcg_solve(int nranks_here, mk_pcg **solvers, mk_dist_matrix **A, mk_vector **b, mk_vector **x);
+/* plain Jacobi (extension id 70) on the distributed operator; residual all-reduced every check_every iterations */
+int mk_dist_jacobi_solve(int nranks_here, mk_jacobi **solvers, mk_dist_matrix **A, mk_vector **b, mk_vector **x);
 
 /* ---- row-block partition: solvers.c:214-231,270-281 with defects Q1-Q4 repaired ----------- */
 /* host-only; rowptr64 has nrows+1 entries; row_start gets nparts+1 entries */

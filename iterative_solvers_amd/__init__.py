@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmi355_krylov.so")
+LIB_PATH = os.environ.get("MK_LIB_PATH") or os.path.join(_HERE, "lib", "libmi355_krylov.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 
@@ -62,7 +62,7 @@ EXPORTS = [
     "mk_partition_rows",
     "mk_comm_get_unique_id", "mk_comm_create", "mk_comm_create_local", "mk_comm_self_test", "mk_comm_destroy",
     "mk_dist_matrix_create", "mk_dist_matrix_destroy", "mk_dist_matrix_get_info",
-    "mk_dist_vector_create", "mk_dist_spmv", "mk_dist_pcg_solve",
+    "mk_dist_vector_create", "mk_dist_spmv", "mk_dist_pcg_solve", "mk_dist_jacobi_solve",
 ]
 
 _lib = None

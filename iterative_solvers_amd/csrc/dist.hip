@@ -191,7 +191,7 @@ __global__ void pack_kernel(int n, const int *__restrict__ idx, const double *__
 // y[rows[i]] += alpha * sum_k val[k] * xghost[col[k]]  over the offd block; with DOT the
 // per-block partial of sum_i (contribution_i * xlocal[rows[i]]) goes to slab component 0
 // (component 1 gets 0) so that <A p, p> can be completed after the diag pass.
-template <int G, bool DOT>
+template <int G, bool DOT, bool SET>
 __global__ __launch_bounds__(256) void offd_spmv_kernel(int nrows, const int *__restrict__ rowptr, const int *__restrict__ col,
                                                         const double *__restrict__ val, const int *__restrict__ rows,
                                                         const double *__restrict__ xghost, const double *__restrict__ xlocal,
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256) void offd_spmv_kernel(int nrows, const int *__
     if (g == 0 && i < nrows) {
       const int r = rows[i];
       const double add = alpha * sum;
-      y[r] += add;
+      if (SET) y[r] = add; else y[r] += add;
       if (DOT) acc += add * xlocal[r];
     }
   }
@@ -419,7 +419,7 @@ static int all_reduce(int R, mk_dist_matrix **A, double **bufs, int count) {
   return MK_OK;
 }
 
-template <bool DOT>
+template <bool DOT, bool SET = false>
 static int launch_offd(const mk_dist_matrix *D, const double *xext, double *y, double alpha, double *slab, const int *done, int *nblocks) {
   Context &c = ctx();
   const int G = D->offd_lanes;
@@ -427,7 +427,7 @@ static int launch_offd(const mk_dist_matrix *D, const double *xext, double *y, d
   int blocks = std::max(1, std::min((D->n_offd_rows + rows_per_block - 1) / rows_per_block, 1024));
   if (nblocks) *nblocks = blocks;
   if (D->n_offd_rows == 0 && !DOT) return MK_OK;
-#define MK_OFFD(GG) case GG: hipLaunchKernelGGL((offd_spmv_kernel<GG, DOT>), dim3(blocks), dim3(256), 0, c.stream, D->n_offd_rows, \
+#define MK_OFFD(GG) case GG: hipLaunchKernelGGL((offd_spmv_kernel<GG, DOT, SET>), dim3(blocks), dim3(256), 0, c.stream, D->n_offd_rows, \
     D->offd.rowptr, D->offd.col, D->offd.val, D->offd_rows, xext + D->n_local, xext, y, alpha, slab, done); break;
   switch (G) { MK_OFFD(1) MK_OFFD(2) MK_OFFD(4) MK_OFFD(8) MK_OFFD(16) MK_OFFD(32) MK_OFFD(64) default: return fail(MK_ERR_INVALID, "offd lanes"); }
 #undef MK_OFFD
@@ -789,6 +789,111 @@ int mk_dist_pcg_solve(int R, mk_pcg **solvers, mk_dist_matrix **A, mk_vector **b
       solvers[r]->norms_cap = S0->max_iter + 1;
       W[r].norms = nullptr;
     }
+  }
+  cleanup();
+#undef MK_D
+#undef MK_DH
+  return MK_OK;
+}
+
+
+// plain Jacobi on the distributed operator (BASELINE config 5).  Per iteration: halo of x,
+// off-rank part of A x into a scratch vector (rows that touch ghosts only), then the fused
+// Jacobi pass over the diag block.  The residual norm is all-reduced only at the iterations
+// where it is tested (every check_every).
+int mk_dist_jacobi_solve(int R, mk_jacobi **solvers, mk_dist_matrix **A, mk_vector **b, mk_vector **x) {
+  MK_REQUIRE_INIT();
+  MK_TRY(check_ranks("mk_dist_jacobi_solve", R, A));
+  if (!solvers || !b || !x) return fail(MK_ERR_INVALID, "mk_dist_jacobi_solve: null argument");
+  Context &c = ctx();
+  mk_jacobi *S0 = solvers[0];
+  for (int r = 0; r < R; r++) {
+    if (!solvers[r] || !b[r] || !x[r]) return fail(MK_ERR_INVALID, "mk_dist_jacobi_solve: null argument");
+    if (b[r]->n != A[r]->n_local || x[r]->n != A[r]->n_local || x[r]->cap < A[r]->n_local + A[r]->n_ghost)
+      return fail(MK_ERR_INVALID, "mk_dist_jacobi_solve: vectors must come from mk_dist_vector_create of the same matrix");
+    if (solvers[r]->max_iter != S0->max_iter || solvers[r]->tol != S0->tol || solvers[r]->check_every != S0->check_every)
+      return fail(MK_ERR_INVALID, "mk_dist_jacobi_solve: ranks disagree on solver settings");
+  }
+  struct JW { double *xalt = nullptr, *extra = nullptr, *slab = nullptr, *buf = nullptr; JacobiState *state = nullptr; };
+  std::vector<JW> W(R);
+  std::vector<double *> cur(R), nxt(R), bufs(R);
+  std::vector<int> blocks(R), vb(R);
+  auto cleanup = [&]() {
+    (void)hipDeviceSynchronize();
+    for (auto &w : W) { dev_free(w.xalt); dev_free(w.extra); dev_free(w.slab); dev_free(w.buf); dev_free(w.state); }
+  };
+  int rc = MK_OK;
+#define MK_D(expr) do { rc = (expr); if (rc != MK_OK) { cleanup(); return rc; } } while (0)
+#define MK_DH(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return fail(MK_ERR_HIP, "%s -> %s", #expr, hipGetErrorString(e_)); } } while (0)
+  for (int r = 0; r < R; r++) {
+    mk_dist_matrix *D = A[r];
+    const size_t nl = (size_t)D->n_local;
+    MK_D(dev_alloc(&W[r].xalt, nl + (size_t)D->n_ghost));
+    MK_D(dev_alloc(&W[r].extra, nl));
+    MK_D(dev_alloc(&W[r].slab, (size_t)kSlabStride));
+    MK_D(dev_alloc(&W[r].buf, 2));
+    MK_D(dev_alloc(&W[r].state, 1));
+    MK_DH(hipMemsetAsync(W[r].extra, 0, sizeof(double) * nl, c.stream));
+    MK_D(analyse_matrix(&D->diag));
+    cur[r] = x[r]->d; nxt[r] = W[r].xalt; bufs[r] = W[r].buf;
+    vb[r] = vec_blocks(D->n_local);
+    const int G = D->diag.lanes;
+    blocks[r] = (int)std::max<int64_t>(1, std::min<int64_t>((D->n_local + 256 / G - 1) / (256 / G), std::min<int64_t>((int64_t)c.num_cus * 8, kSlabStride)));
+    solvers[r]->iterations = 0; solvers[r]->rel_res_norm = 0.0; solvers[r]->converged = 0;
+  }
+  JacobiState *hst = static_cast<JacobiState *>(c.pinned);
+  // ||b||^2
+  for (int r = 0; r < R; r++) {
+    hipLaunchKernelGGL(dot_self_kernel, dim3(vb[r]), dim3(256), 0, c.stream, A[r]->n_local, b[r]->d, W[r].slab);
+    hipLaunchKernelGGL((finalize_slab_kernel<1>), dim3(1), dim3(kVecThreads), 0, c.stream, W[r].slab, vb[r], W[r].buf);
+  }
+  MK_D(all_reduce(R, A, bufs.data(), 1));
+  for (int r = 0; r < R; r++) hipLaunchKernelGGL(jacobi_init_kernel, dim3(1), dim3(256), 0, c.stream, W[r].buf, 1, 1, S0->tol, W[r].state);
+  MK_DH(hipMemcpyAsync(hst, W[0].state, sizeof(JacobiState), hipMemcpyDeviceToHost, c.stream));
+  MK_DH(hipStreamSynchronize(c.stream));
+  if (!(hst->bb > 0.0)) {
+    for (int r = 0; r < R; r++)
+      if (A[r]->n_local) hipLaunchKernelGGL(copy_kernel, dim3(vb[r]), dim3(256), 0, c.stream, x[r]->d, b[r]->d, A[r]->n_local);
+    cleanup();
+    return MK_OK;
+  }
+  long long k = 0;
+  int checks = 0;
+  for (;;) {
+    MK_D(halo_exchange(R, A, cur.data(), false));
+    for (int r = 0; r < R; r++) {
+      mk_dist_matrix *D = A[r];
+      MK_D((launch_offd<false, true>(D, cur[r], W[r].extra, 1.0, nullptr, &W[r].state->done, nullptr)));
+      const mk_matrix &M = D->diag;
+#define MK_JSTEP(GG) case GG: hipLaunchKernelGGL((jacobi_step_kernel<GG>), dim3(blocks[r]), dim3(256), 0, c.stream, D->n_local, M.rowptr, M.col, M.val, b[r]->d, cur[r], nxt[r], W[r].slab, W[r].state, (const double *)W[r].extra); break;
+      switch (M.lanes) { MK_JSTEP(1) MK_JSTEP(2) MK_JSTEP(4) MK_JSTEP(8) MK_JSTEP(16) MK_JSTEP(32) MK_JSTEP(64)
+        default: cleanup(); return fail(MK_ERR_INVALID, "jacobi: bad lanes per row %d", M.lanes); }
+#undef MK_JSTEP
+    }
+    const bool last = (k >= S0->max_iter);
+    if (k % S0->check_every == 0 || last) {
+      for (int r = 0; r < R; r++)
+        hipLaunchKernelGGL((finalize_slab_kernel<1>), dim3(1), dim3(kVecThreads), 0, c.stream, W[r].slab, blocks[r], W[r].buf);
+      MK_D(all_reduce(R, A, bufs.data(), 1));
+      for (int r = 0; r < R; r++)
+        hipLaunchKernelGGL(jacobi_check_kernel, dim3(1), dim3(256), 0, c.stream, W[r].buf, 1, 1, k, W[r].state);
+      checks++;
+      if (last || checks % 4 == 0) {
+        MK_DH(hipMemcpyAsync(hst, W[0].state, sizeof(JacobiState), hipMemcpyDeviceToHost, c.stream));
+        MK_DH(hipStreamSynchronize(c.stream));
+        if (hst->done != 0 || last) break;
+      }
+    }
+    for (int r = 0; r < R; r++) std::swap(cur[r], nxt[r]);
+    k++;
+  }
+  MK_DH(hipGetLastError());
+  for (int r = 0; r < R; r++) {
+    solvers[r]->iterations = hst->iter;
+    solvers[r]->converged = hst->converged;
+    solvers[r]->rel_res_norm = sqrt(hst->rr / hst->bb);
+    if ((hst->iter & 1) && A[r]->n_local)
+      hipLaunchKernelGGL(copy_kernel, dim3(vb[r]), dim3(256), 0, c.stream, x[r]->d, W[r].xalt, A[r]->n_local);
   }
   cleanup();
 #undef MK_D

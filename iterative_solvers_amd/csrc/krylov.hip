@@ -206,105 +206,6 @@ int mk_pcg_destroy(mk_pcg *S) {
 //   x_{k+1} = x_k + D^-1 (b - A x_k), D taken from the row itself while it streams by;
 //   the same pass yields ||b - A x_k||^2, tested every check_every iterations.
 // Algorithmic bytes per iteration: 12*nnz + 28*n.
-namespace mk {
-
-struct JacobiState {
-  double rr, bb, eps;
-  long long iter;
-  int done;
-  int converged;
-};
-
-template <int G>
-__global__ __launch_bounds__(256) void jacobi_step_kernel(int64_t nrows, const int *__restrict__ rowptr,
-                                                           const int *__restrict__ col, const double *__restrict__ val,
-                                                           const double *__restrict__ b, const double *__restrict__ xold,
-                                                           double *__restrict__ xnew, double *__restrict__ slab,
-                                                           const JacobiState *st) {
-  if (st->done != 0) return;
-  constexpr int ROWS = 256 / G;
-  const int g = threadIdx.x % G, rl = threadIdx.x / G;
-  double acc = 0.0;
-  for (int64_t base = (int64_t)blockIdx.x * ROWS; base < nrows; base += (int64_t)gridDim.x * ROWS) {
-    const int64_t row = base + rl;
-    double sum = 0.0, dv = 0.0;
-    int dj = -1;
-    if (row < nrows) {
-      const int bgn = rowptr[row], end = rowptr[row + 1];
-      for (int j = bgn + g; j < end; j += G) {
-        const int cj = col[j];
-        const double vj = val[j];
-        sum += vj * xold[cj];
-        if (cj == (int)row) { dj = j; dv = vj; }   // the last stored diagonal entry wins, as in a serial sweep
-      }
-    }
-#pragma unroll
-    for (int off = G / 2; off > 0; off >>= 1) {
-      sum += __shfl_down(sum, off, G);
-      const int oj = __shfl_down(dj, off, G);
-      const double ov = __shfl_down(dv, off, G);
-      if (oj > dj) { dj = oj; dv = ov; }
-    }
-    if (g == 0 && row < nrows) {
-      const double res = b[row] - sum;
-      acc += res * res;
-      xnew[row] = xold[row] + res / dv;
-    }
-  }
-  __shared__ double smem[256 / 64];
-  double v[1] = {acc};
-  block_sum<1, 256>(v, smem);
-  if (threadIdx.x == 0) slab[blockIdx.x] = v[0];
-}
-
-__global__ __launch_bounds__(256) void jacobi_check_kernel(const double *slab, int nblocks, long long k, JacobiState *st) {
-  if (st->done != 0) return;
-  __shared__ double smem[256 / 64];
-  double v[1];
-  reduce_slab<1, 256>(slab, nblocks, kSlabStride, v, smem);
-  if (threadIdx.x == 0) {
-    st->rr = v[0];
-    st->iter = k;
-    if (v[0] / st->bb < st->eps) { st->converged = 1; st->done = 1; }
-  }
-}
-
-__global__ __launch_bounds__(256) void dot_self_kernel(int64_t n, const double *__restrict__ a, double *__restrict__ slab) {
-  double v[1] = {0.0};
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) v[0] += a[i] * a[i];
-  __shared__ double smem[256 / 64];
-  block_sum<1, 256>(v, smem);
-  if (threadIdx.x == 0) slab[blockIdx.x] = v[0];
-}
-
-__global__ __launch_bounds__(256) void jacobi_init_kernel(const double *slab, int nblocks, double tol, JacobiState *st) {
-  __shared__ double smem[256 / 64];
-  double v[1];
-  reduce_slab<1, 256>(slab, nblocks, kSlabStride, v, smem);
-  if (threadIdx.x == 0) {
-    JacobiState s;
-    memset(&s, 0, sizeof(s));
-    s.bb = v[0];
-    s.eps = tol * tol;
-    s.done = (v[0] > 0.0) ? 0 : 1;
-    *st = s;
-  }
-}
-
-}  // namespace mk
-
-struct mk_jacobi {
-  int max_iter = 1000;
-  double tol = 1e-6;
-  int check_every = 10;
-  int64_t n = 0;
-  double *xalt = nullptr, *slab = nullptr;
-  mk::JacobiState *state = nullptr;
-  long long iterations = 0;
-  double rel_res_norm = 0.0;
-  int converged = 0;
-};
-
 extern "C" {
 
 int mk_jacobi_create(mk_jacobi **solver) {
@@ -353,7 +254,7 @@ int mk_jacobi_solve(mk_jacobi *S, const mk_matrix *A, const mk_vector *b, mk_vec
   JacobiState *hst = static_cast<JacobiState *>(c.pinned);
   const int vb = vec_blocks(n);
   hipLaunchKernelGGL(dot_self_kernel, dim3(vb), dim3(256), 0, c.stream, n, b->d, S->slab);
-  hipLaunchKernelGGL(jacobi_init_kernel, dim3(1), dim3(256), 0, c.stream, S->slab, vb, S->tol, S->state);
+  hipLaunchKernelGGL(jacobi_init_kernel, dim3(1), dim3(256), 0, c.stream, S->slab, vb, kSlabStride, S->tol, S->state);
   MK_HIP(hipMemcpyAsync(hst, S->state, sizeof(JacobiState), hipMemcpyDeviceToHost, c.stream));
   MK_HIP(hipStreamSynchronize(c.stream));
   if (!(hst->bb > 0.0)) {
@@ -368,13 +269,13 @@ int mk_jacobi_solve(mk_jacobi *S, const mk_matrix *A, const mk_vector *b, mk_vec
   long long k = 0;
   int checks = 0;
   for (;;) {
-#define MK_JSTEP(GG) case GG: hipLaunchKernelGGL((jacobi_step_kernel<GG>), dim3(blocks), dim3(256), 0, c.stream, n, A->rowptr, A->col, A->val, b->d, cur, nxt, S->slab, S->state); break;
+#define MK_JSTEP(GG) case GG: hipLaunchKernelGGL((jacobi_step_kernel<GG>), dim3(blocks), dim3(256), 0, c.stream, n, A->rowptr, A->col, A->val, b->d, cur, nxt, S->slab, S->state, (const double *)nullptr); break;
     switch (G) { MK_JSTEP(1) MK_JSTEP(2) MK_JSTEP(4) MK_JSTEP(8) MK_JSTEP(16) MK_JSTEP(32) MK_JSTEP(64)
       default: return fail(MK_ERR_INVALID, "jacobi: bad lanes per row %d", G); }
 #undef MK_JSTEP
     const bool last = (k >= S->max_iter);
     if (k % S->check_every == 0 || last) {
-      hipLaunchKernelGGL(jacobi_check_kernel, dim3(1), dim3(256), 0, c.stream, S->slab, blocks, k, S->state);
+      hipLaunchKernelGGL(jacobi_check_kernel, dim3(1), dim3(256), 0, c.stream, S->slab, blocks, kSlabStride, k, S->state);
       checks++;
       // read the flag back every 4th check (and at the end); later steps are no-ops once it is set
       if (last || checks % 4 == 0) {

@@ -216,3 +216,104 @@ struct mk_pcg {
   int converged = 0, breakdown = 0;
 };
 
+// ---- plain Jacobi iteration (extension id 70): kernels shared with dist.hip
+namespace mk {
+
+struct JacobiState {
+  double rr, bb, eps;
+  long long iter;
+  int done;
+  int converged;
+};
+
+template <int G>
+static __global__ __launch_bounds__(256) void jacobi_step_kernel(int64_t nrows, const int *__restrict__ rowptr,
+                                                           const int *__restrict__ col, const double *__restrict__ val,
+                                                           const double *__restrict__ b, const double *__restrict__ xold,
+                                                           double *__restrict__ xnew, double *__restrict__ slab,
+                                                           const JacobiState *st, const double *__restrict__ extra) {
+  if (st->done != 0) return;
+  constexpr int ROWS = 256 / G;
+  const int g = threadIdx.x % G, rl = threadIdx.x / G;
+  double acc = 0.0;
+  for (int64_t base = (int64_t)blockIdx.x * ROWS; base < nrows; base += (int64_t)gridDim.x * ROWS) {
+    const int64_t row = base + rl;
+    double sum = 0.0, dv = 0.0;
+    int dj = -1;
+    if (row < nrows) {
+      const int bgn = rowptr[row], end = rowptr[row + 1];
+      for (int j = bgn + g; j < end; j += G) {
+        const int cj = col[j];
+        const double vj = val[j];
+        sum += vj * xold[cj];
+        if (cj == (int)row) { dj = j; dv = vj; }   // the last stored diagonal entry wins, as in a serial sweep
+      }
+    }
+#pragma unroll
+    for (int off = G / 2; off > 0; off >>= 1) {
+      sum += __shfl_down(sum, off, G);
+      const int oj = __shfl_down(dj, off, G);
+      const double ov = __shfl_down(dv, off, G);
+      if (oj > dj) { dj = oj; dv = ov; }
+    }
+    if (g == 0 && row < nrows) {
+      const double res = extra ? (b[row] - sum) - extra[row] : b[row] - sum;   // extra = off-rank part of A x
+      acc += res * res;
+      xnew[row] = xold[row] + res / dv;
+    }
+  }
+  __shared__ double smem[256 / 64];
+  double v[1] = {acc};
+  block_sum<1, 256>(v, smem);
+  if (threadIdx.x == 0) slab[blockIdx.x] = v[0];
+}
+
+static __global__ __launch_bounds__(256) void jacobi_check_kernel(const double *slab, int nblocks, int stride, long long k, JacobiState *st) {
+  if (st->done != 0) return;
+  __shared__ double smem[256 / 64];
+  double v[1];
+  reduce_slab<1, 256>(slab, nblocks, stride, v, smem);
+  if (threadIdx.x == 0) {
+    st->rr = v[0];
+    st->iter = k;
+    if (v[0] / st->bb < st->eps) { st->converged = 1; st->done = 1; }
+  }
+}
+
+static __global__ __launch_bounds__(256) void dot_self_kernel(int64_t n, const double *__restrict__ a, double *__restrict__ slab) {
+  double v[1] = {0.0};
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) v[0] += a[i] * a[i];
+  __shared__ double smem[256 / 64];
+  block_sum<1, 256>(v, smem);
+  if (threadIdx.x == 0) slab[blockIdx.x] = v[0];
+}
+
+static __global__ __launch_bounds__(256) void jacobi_init_kernel(const double *slab, int nblocks, int stride, double tol, JacobiState *st) {
+  __shared__ double smem[256 / 64];
+  double v[1];
+  reduce_slab<1, 256>(slab, nblocks, stride, v, smem);
+  if (threadIdx.x == 0) {
+    JacobiState s;
+    memset(&s, 0, sizeof(s));
+    s.bb = v[0];
+    s.eps = tol * tol;
+    s.done = (v[0] > 0.0) ? 0 : 1;
+    *st = s;
+  }
+}
+
+}  // namespace mk
+
+
+struct mk_jacobi {
+  int max_iter = 1000;
+  double tol = 1e-6;
+  int check_every = 10;
+  int64_t n = 0;
+  double *xalt = nullptr, *slab = nullptr;
+  mk::JacobiState *state = nullptr;
+  long long iterations = 0;
+  double rel_res_norm = 0.0;
+  int converged = 0;
+};
+

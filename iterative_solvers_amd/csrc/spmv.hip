@@ -331,7 +331,9 @@ typedef int i4_t __attribute__((ext_vector_type(4)));
 // the barrier (loads retire in order: anything issued BEFORE the gathers would be waited
 // for with them).
 // COMP: column indices come from the pattern table (pat/ptab, staged in LDS) instead of col[].
-template <int G, int MODE, int U, bool COMP>
+// NT: the matrix exceeds the 256 MB Infinity Cache, so its values are loaded non-temporally and
+// leave the cache to x (measured: +5..8 % on 512^3; on cache-resident matrices plain loads win by 20 %).
+template <int G, int MODE, int U, bool COMP, bool NT>
 __global__ __launch_bounds__(kThreads) void spmv_stream_kernel(
     int64_t nrows, const int *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ val,
     const double *__restrict__ x, double *__restrict__ y, double alpha, double beta, double *__restrict__ slab,
@@ -363,7 +365,7 @@ __global__ __launch_bounds__(kThreads) void spmv_stream_kernel(
 #pragma unroll
     for (int i = 0; i < NV; i++) {
       const int k = vb_ + (tid + i * kThreads) * 2;
-      if (k < ce_) rv[i] = *reinterpret_cast<const d2_t *>(val + k);
+      if (k < ce_) rv[i] = NT ? __builtin_nontemporal_load(reinterpret_cast<const d2_t *>(val + k)) : *reinterpret_cast<const d2_t *>(val + k);
     }
 #pragma unroll
     for (int i = 0; i < NI; i++) {
@@ -455,7 +457,7 @@ __global__ __launch_bounds__(kThreads) void spmv_stream_kernel(
   }
 }
 
-template <int MODE, int U, bool COMP>
+template <int MODE, int U, bool COMP, bool NT>
 static int launch_stream_u(const mk_matrix *A, double alpha, const double *x, double beta, double *y, double *slab,
                            const int *done, int *nblocks) {
   Context &c = ctx();
@@ -469,7 +471,7 @@ static int launch_stream_u(const mk_matrix *A, double alpha, const double *x, do
   if (per_cu <= 0) {
     int occ = 0;
     hipError_t oe = hipErrorInvalidValue;
-#define MK_OCC_S(GG) case GG: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, spmv_stream_kernel<GG, MODE, U, COMP>, kThreads, lds); break;
+#define MK_OCC_S(GG) case GG: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, spmv_stream_kernel<GG, MODE, U, COMP, NT>, kThreads, lds); break;
     switch (G) { MK_OCC_S(1) MK_OCC_S(2) MK_OCC_S(4) MK_OCC_S(8) MK_OCC_S(16) MK_OCC_S(32) MK_OCC_S(64) default: break; }
 #undef MK_OCC_S
     per_cu = (oe == hipSuccess && occ > 0) ? std::min(occ, 8) : 4;
@@ -480,7 +482,7 @@ static int launch_stream_u(const mk_matrix *A, double alpha, const double *x, do
   if (nblocks) *nblocks = (int)blocks;
 #define MK_LAUNCH_S(GG)                                                                                            \
   case GG:                                                                                                         \
-    hipLaunchKernelGGL((spmv_stream_kernel<GG, MODE, U, COMP>), dim3((unsigned)blocks), dim3(kThreads), lds,      \
+    hipLaunchKernelGGL((spmv_stream_kernel<GG, MODE, U, COMP, NT>), dim3((unsigned)blocks), dim3(kThreads), lds,      \
                        c.stream, A->nrows, A->rowptr, A->col, A->val, x, y, alpha, beta, slab, done, cap, A->pat,  \
                        A->ptab, tab_ints, A->pml);                                                                 \
     break;
@@ -504,15 +506,19 @@ template <int MODE>
 static int launch_stream(const mk_matrix *A, double alpha, const double *x, double beta, double *y, double *slab,
                          const int *done, int *nblocks) {
   const int cap = A->stream_cap;
-  if (A->pat) {
-    if (cap <= 1024 * 1 - 8) return launch_stream_u<MODE, 1, true>(A, alpha, x, beta, y, slab, done, nblocks);
-    if (cap <= 1024 * 2 - 8) return launch_stream_u<MODE, 2, true>(A, alpha, x, beta, y, slab, done, nblocks);
-    if (cap <= 1024 * 3 - 8) return launch_stream_u<MODE, 3, true>(A, alpha, x, beta, y, slab, done, nblocks);
-  } else {
-    if (cap <= 1024 * 1 - 8) return launch_stream_u<MODE, 1, false>(A, alpha, x, beta, y, slab, done, nblocks);
-    if (cap <= 1024 * 2 - 8) return launch_stream_u<MODE, 2, false>(A, alpha, x, beta, y, slab, done, nblocks);
-    if (cap <= 1024 * 3 - 8) return launch_stream_u<MODE, 3, false>(A, alpha, x, beta, y, slab, done, nblocks);
+  // values larger than the Infinity Cache are streamed non-temporally
+  const bool nt = (double)A->nnz * 8.0 > 200e6;
+#define MK_STREAM_PICK(UU)                                                                                         \
+  if (cap <= 1024 * UU - 8) {                                                                                      \
+    if (A->pat) return nt ? launch_stream_u<MODE, UU, true, true>(A, alpha, x, beta, y, slab, done, nblocks)       \
+                          : launch_stream_u<MODE, UU, true, false>(A, alpha, x, beta, y, slab, done, nblocks);     \
+    return nt ? launch_stream_u<MODE, UU, false, true>(A, alpha, x, beta, y, slab, done, nblocks)                  \
+              : launch_stream_u<MODE, UU, false, false>(A, alpha, x, beta, y, slab, done, nblocks);                \
   }
+  MK_STREAM_PICK(1)
+  MK_STREAM_PICK(2)
+  MK_STREAM_PICK(3)
+#undef MK_STREAM_PICK
   return fail(MK_ERR_UNSUPPORTED, "spmv: stream capacity %d too large", cap);
 }
 

@@ -30,13 +30,14 @@ def _lib():
         L.mk_dist_vector_create.argtypes = [P, C.POINTER(P)]
         L.mk_dist_spmv.argtypes = [C.c_int, C.POINTER(P), C.POINTER(P), C.POINTER(P)]
         L.mk_dist_pcg_solve.argtypes = [C.c_int, C.POINTER(P), C.POINTER(P), C.POINTER(P), C.POINTER(P)]
+        L.mk_dist_jacobi_solve.argtypes = [C.c_int, C.POINTER(P), C.POINTER(P), C.POINTER(P), C.POINTER(P)]
         _sigs_done = True
     return L
 
 
 DIST_EXPORTS = ["mk_comm_get_unique_id", "mk_comm_create", "mk_comm_create_local", "mk_comm_self_test", "mk_comm_destroy",
                 "mk_dist_matrix_create", "mk_dist_matrix_destroy", "mk_dist_matrix_get_info",
-                "mk_dist_vector_create", "mk_dist_spmv", "mk_dist_pcg_solve"]
+                "mk_dist_vector_create", "mk_dist_spmv", "mk_dist_pcg_solve", "mk_dist_jacobi_solve"]
 
 
 # ------------------------------------------------------------------ host-side helpers (no GPU)
@@ -163,6 +164,19 @@ def dist_pcg_solve(solvers, As, bs, xs):
         _ck(L.mk_pcg_get_final_relative_residual_norm(S.h, C.byref(nrm)))
         _ck(L.mk_pcg_get_converged(S.h, C.byref(cv), C.byref(bd)))
         out.append(dict(iterations=it.value, rel_res_norm=nrm.value, converged=cv.value, breakdown=bd.value))
+    return out
+
+
+def dist_jacobi_solve(solvers, As, bs, xs):
+    L = _lib()
+    _ck(L.mk_dist_jacobi_solve(len(As), _arr(solvers), _arr(As), _arr(bs), _arr(xs)))
+    out = []
+    for S in solvers:
+        it, nrm, cv = C.c_longlong(), C.c_double(), C.c_int()
+        _ck(L.mk_jacobi_get_num_iterations(S.h, C.byref(it)))
+        _ck(L.mk_jacobi_get_final_relative_residual_norm(S.h, C.byref(nrm)))
+        _ck(L.mk_jacobi_get_converged(S.h, C.byref(cv)))
+        out.append(dict(iterations=it.value, rel_res_norm=nrm.value, converged=cv.value))
     return out
 
 

@@ -103,6 +103,26 @@ def test_dist_pcg_maxit_and_empty_rank():
     assert np.allclose(np.concatenate([x.get() for x in xs]), o["x"], rtol=1e-9)
 
 
+@pytest.mark.parametrize("world", [1, 2, 5])
+def test_dist_jacobi_banded_matches_oracle(world):
+    # BASELINE config 5 shape scaled down: banded, half bandwidth 3, diagonally dominant
+    n = 30000
+    rp, ci, v = oracle.banded_csr(n, 3)
+    o = oracle.jacobi(rp, ci, v, np.ones(n), tol=1e-9, maxit=400, check_every=10)
+    rs = mkd.even_row_start(n, world)
+    comms = mkd.Comm.local_world(world) if world > 1 else [None]
+    As = _blocks(rp, ci, v, n, rs, comms)
+    bs = [A.vector(fill=1.0) for A in As]
+    xs = [A.vector(fill=0.0) for A in As]
+    Ss = [mk.Jacobi(max_iter=400, tol=1e-9, check_every=10) for _ in As]
+    res = mkd.dist_jacobi_solve(Ss, As, bs, xs)
+    assert res[0]["converged"] == 1 == o["converged"] and res[0]["iterations"] == o["iterations"]
+    assert np.isclose(res[0]["rel_res_norm"], o["rel_res_norm"], rtol=1e-9)
+    assert np.allclose(np.concatenate([x.get() for x in xs]), o["x"], rtol=1e-12, atol=0)
+    if world > 1:
+        assert As[0].info()["n_ghost"] == 3 and As[1].info()["n_offd_rows"] in (3, 6)
+
+
 def test_dist_errors():
     rp, ci, v = oracle.stencil_csr(5, 8, 8)
     comms = mkd.Comm.local_world(2)
