@@ -865,10 +865,19 @@ int mk_dist_jacobi_solve(int R, mk_jacobi **solvers, mk_dist_matrix **A, mk_vect
       mk_dist_matrix *D = A[r];
       MK_D((launch_offd<false, true>(D, cur[r], W[r].extra, 1.0, nullptr, &W[r].state->done, nullptr)));
       const mk_matrix &M = D->diag;
+      int sweep_blocks = 0;
+      const int src = launch_jacobi_sweep(&D->diag, b[r]->d, W[r].extra, cur[r], nxt[r], W[r].slab, &W[r].state->done, &sweep_blocks);
+      if (src == MK_OK) {
+        blocks[r] = sweep_blocks;
+      } else if (src == MK_ERR_UNSUPPORTED) {
 #define MK_JSTEP(GG) case GG: hipLaunchKernelGGL((jacobi_step_kernel<GG>), dim3(blocks[r]), dim3(256), 0, c.stream, D->n_local, M.rowptr, M.col, M.val, b[r]->d, cur[r], nxt[r], W[r].slab, W[r].state, (const double *)W[r].extra); break;
       switch (M.lanes) { MK_JSTEP(1) MK_JSTEP(2) MK_JSTEP(4) MK_JSTEP(8) MK_JSTEP(16) MK_JSTEP(32) MK_JSTEP(64)
         default: cleanup(); return fail(MK_ERR_INVALID, "jacobi: bad lanes per row %d", M.lanes); }
 #undef MK_JSTEP
+      } else {
+        cleanup();
+        return src;
+      }
     }
     const bool last = (k >= S0->max_iter);
     if (k % S0->check_every == 0 || last) {

@@ -269,10 +269,18 @@ int mk_jacobi_solve(mk_jacobi *S, const mk_matrix *A, const mk_vector *b, mk_vec
   long long k = 0;
   int checks = 0;
   for (;;) {
+    int sweep_blocks = 0;
+    int src = launch_jacobi_sweep(A, b->d, nullptr, cur, nxt, S->slab, &S->state->done, &sweep_blocks);
+    if (src == MK_OK) {
+      blocks = sweep_blocks;
+    } else if (src == MK_ERR_UNSUPPORTED) {
 #define MK_JSTEP(GG) case GG: hipLaunchKernelGGL((jacobi_step_kernel<GG>), dim3(blocks), dim3(256), 0, c.stream, n, A->rowptr, A->col, A->val, b->d, cur, nxt, S->slab, S->state, (const double *)nullptr); break;
     switch (G) { MK_JSTEP(1) MK_JSTEP(2) MK_JSTEP(4) MK_JSTEP(8) MK_JSTEP(16) MK_JSTEP(32) MK_JSTEP(64)
       default: return fail(MK_ERR_INVALID, "jacobi: bad lanes per row %d", G); }
 #undef MK_JSTEP
+    } else {
+      return src;
+    }
     const bool last = (k >= S->max_iter);
     if (k % S->check_every == 0 || last) {
       hipLaunchKernelGGL(jacobi_check_kernel, dim3(1), dim3(256), 0, c.stream, S->slab, blocks, kSlabStride, k, S->state);

@@ -127,6 +127,11 @@ int launch_spmv(const mk_matrix *A, double alpha, const double *x, double beta, 
 // `done` (may be null) is a device flag: nonzero -> kernel returns at once.
 int launch_spmv_dot(const mk_matrix *A, const double *x, double *y, double *slab, const int *done, int *nblocks);
 
+// xnew = xold + D^-1 (rhs - A xold - extra) with the partial of the squared residual in slab component 0;
+// MK_ERR_UNSUPPORTED (no error text) when A is not served by the stream kernel
+int launch_jacobi_sweep(const mk_matrix *A, const double *rhs, const double *extra, const double *xold, double *xnew,
+                        double *slab, const int *done, int *nblocks);
+
 int exclusive_scan_u32(const uint32_t *in, uint32_t *out, size_t n, uint32_t *total_out_dev);
 
 // device COO -> CSR (stable by row).  Takes ownership of rows/cols/vals buffers of `coo`

@@ -338,7 +338,9 @@ __global__ __launch_bounds__(kThreads) void spmv_stream_kernel(
     int64_t nrows, const int *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ val,
     const double *__restrict__ x, double *__restrict__ y, double alpha, double beta, double *__restrict__ slab,
     const int *__restrict__ done, int cap, const unsigned short *__restrict__ pat, const int *__restrict__ ptab,
-    int tab_ints, int pml) {
+    int tab_ints, int pml, const double *__restrict__ rhs, const double *__restrict__ extra) {
+  // MODE 2 = one Jacobi sweep: y = x + D^-1 (rhs - A x - extra), D picked up from the row while it
+  // streams by; slab component 0 receives the partial of ||rhs - A x - extra||^2
   if (done != nullptr && *done != 0) return;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   double *sval = reinterpret_cast<double *>(smem_raw);                     // cap + 2 doubles
@@ -415,8 +417,10 @@ __global__ __launch_bounds__(kThreads) void spmv_stream_kernel(
     }
 #pragma unroll
     for (int t = 0; t < 8; t++) xj[t] = any ? x[cj[t]] : 0.0;
-    const double xr = (MODE == 1 && g == 0 && have_row) ? x[row] : 0.0;
+    const double xr = (MODE != 0 && g == 0 && have_row) ? x[row] : 0.0;
     const double yold = (MODE == 0 && g == 0 && have_row && beta != 0.0) ? y[row] : 0.0;
+    double rhs_r = 0.0;
+    if (MODE == 2 && g == 0 && have_row) rhs_r = extra ? rhs[row] - extra[row] : rhs[row];
     // prefetch the next chunk (stays in flight while this one is reduced)
     const int64_t next = chunk + slots;
     int ncb = 0, nce = 0;
@@ -428,15 +432,37 @@ __global__ __launch_bounds__(kThreads) void spmv_stream_kernel(
       nce = rowptr[nr1];
       stage_loads(ncb, nce);
     }
-    double sum = 0.0;
+    double sum = 0.0, dv = 0.0;
+    int dj = -1;
 #pragma unroll
     for (int t = 0; t < 8; t++)
-      if (have_row && b + g + t * G < e) sum += vj[t] * xj[t];
-    for (int j = b + g + 8 * G; j < e; j += G) sum += sv[j] * x[sc[j] + cadd];   // rows longer than 8 lanes' worth
-    if (G > 1) sum = group_sum<G>(sum);
+      if (have_row && b + g + t * G < e) {
+        sum += vj[t] * xj[t];
+        if (MODE == 2 && cj[t] == (int)row) { dj = b + g + t * G; dv = vj[t]; }   // the last stored diagonal entry wins
+      }
+    for (int j = b + g + 8 * G; j < e; j += G) {   // rows longer than 8 lanes' worth
+      const int cc = sc[j] + cadd;
+      sum += sv[j] * x[cc];
+      if (MODE == 2 && cc == (int)row) { dj = j; dv = sv[j]; }
+    }
+    if (G > 1) {
+      sum = group_sum<G>(sum);
+      if (MODE == 2) {
+#pragma unroll
+        for (int off = G / 2; off > 0; off >>= 1) {
+          const int oj = __shfl_down(dj, off, G);
+          const double ov = __shfl_down(dv, off, G);
+          if (oj > dj) { dj = oj; dv = ov; }
+        }
+      }
+    }
     if (g == 0 && have_row) {
       if (MODE == 0) {
         y[row] = (beta == 0.0) ? alpha * sum : alpha * sum + beta * yold;
+      } else if (MODE == 2) {
+        const double res = rhs_r - sum;
+        y[row] = xr + res / dv;
+        acc_yx += res * res;
       } else {
         y[row] = sum;
         acc_yx += sum * xr;
@@ -446,20 +472,20 @@ __global__ __launch_bounds__(kThreads) void spmv_stream_kernel(
     __syncthreads();
     chunk = next; cb = ncb; ce = nce; r0 = nr0; r1 = nr1;
   }
-  if (MODE == 1) {
+  if (MODE != 0) {
     double *red = reinterpret_cast<double *>(smem_raw);
     double v[2] = {acc_yx, acc_xx};
     block_sum<2, kThreads>(v, red);
     if (threadIdx.x == 0) {
       slab[0 * kSlabStride + blockIdx.x] = v[0];
-      slab[1 * kSlabStride + blockIdx.x] = v[1];
+      if (MODE == 1) slab[1 * kSlabStride + blockIdx.x] = v[1];
     }
   }
 }
 
 template <int MODE, int U, bool COMP, bool NT>
 static int launch_stream_u(const mk_matrix *A, double alpha, const double *x, double beta, double *y, double *slab,
-                           const int *done, int *nblocks) {
+                           const int *done, int *nblocks, const double *rhs = nullptr, const double *extra = nullptr) {
   Context &c = ctx();
   const int G = A->stream_lanes, cap = A->stream_cap;
   const int tab_ints = COMP ? A->npat * (A->pml + 1) : 0;
@@ -484,7 +510,7 @@ static int launch_stream_u(const mk_matrix *A, double alpha, const double *x, do
   case GG:                                                                                                         \
     hipLaunchKernelGGL((spmv_stream_kernel<GG, MODE, U, COMP, NT>), dim3((unsigned)blocks), dim3(kThreads), lds,      \
                        c.stream, A->nrows, A->rowptr, A->col, A->val, x, y, alpha, beta, slab, done, cap, A->pat,  \
-                       A->ptab, tab_ints, A->pml);                                                                 \
+                       A->ptab, tab_ints, A->pml, rhs, extra);                                                     \
     break;
   switch (G) {
     MK_LAUNCH_S(1)
@@ -504,16 +530,16 @@ static int launch_stream_u(const mk_matrix *A, double alpha, const double *x, do
 
 template <int MODE>
 static int launch_stream(const mk_matrix *A, double alpha, const double *x, double beta, double *y, double *slab,
-                         const int *done, int *nblocks) {
+                         const int *done, int *nblocks, const double *rhs = nullptr, const double *extra = nullptr) {
   const int cap = A->stream_cap;
   // values larger than the Infinity Cache are streamed non-temporally
   const bool nt = (double)A->nnz * 8.0 > 200e6;
 #define MK_STREAM_PICK(UU)                                                                                         \
   if (cap <= 1024 * UU - 8) {                                                                                      \
-    if (A->pat) return nt ? launch_stream_u<MODE, UU, true, true>(A, alpha, x, beta, y, slab, done, nblocks)       \
-                          : launch_stream_u<MODE, UU, true, false>(A, alpha, x, beta, y, slab, done, nblocks);     \
-    return nt ? launch_stream_u<MODE, UU, false, true>(A, alpha, x, beta, y, slab, done, nblocks)                  \
-              : launch_stream_u<MODE, UU, false, false>(A, alpha, x, beta, y, slab, done, nblocks);                \
+    if (A->pat) return nt ? launch_stream_u<MODE, UU, true, true>(A, alpha, x, beta, y, slab, done, nblocks, rhs, extra)   \
+                          : launch_stream_u<MODE, UU, true, false>(A, alpha, x, beta, y, slab, done, nblocks, rhs, extra); \
+    return nt ? launch_stream_u<MODE, UU, false, true>(A, alpha, x, beta, y, slab, done, nblocks, rhs, extra)              \
+              : launch_stream_u<MODE, UU, false, false>(A, alpha, x, beta, y, slab, done, nblocks, rhs, extra);            \
   }
   MK_STREAM_PICK(1)
   MK_STREAM_PICK(2)
@@ -696,6 +722,15 @@ int launch_spmv(const mk_matrix *A, double alpha, const double *x, double beta, 
   if (A->kernel == MK_SPMV_STREAM) return launch_stream<0>(A, alpha, x, beta, y, nullptr, nullptr, nullptr);
   if (A->kernel == MK_SPMV_SPLIT) return launch_split<0>(A, alpha, x, beta, y, nullptr, nullptr, nullptr);
   return launch_vector<0>(A, alpha, x, beta, y, nullptr, nullptr, nullptr);
+}
+
+// one Jacobi sweep through the stream kernel; returns MK_ERR_UNSUPPORTED when the matrix does not
+// use that kernel (the caller then runs its own lane-per-row sweep)
+int launch_jacobi_sweep(const mk_matrix *A, const double *rhs, const double *extra, const double *xold, double *xnew,
+                        double *slab, const int *done, int *nblocks) {
+  MK_TRY(analyse_matrix(const_cast<mk_matrix *>(A)));
+  if (A->kernel != MK_SPMV_STREAM) return MK_ERR_UNSUPPORTED;
+  return launch_stream<2>(A, 1.0, xold, 0.0, xnew, slab, done, nblocks, rhs, extra);
 }
 
 int launch_spmv_dot(const mk_matrix *A, const double *x, double *y, double *slab, const int *done, int *nblocks) {
