@@ -101,6 +101,7 @@ struct mk_matrix {
   unsigned short *pat = nullptr;   // pattern id per row
   int *ptab = nullptr;             // npat x (pml+1) ints: length, offsets
   int npat = 0, pml = 0;
+  int max_off = 0;                 // largest |column - row| over all patterns
   // split kernel: chunk c covers entries [c*kSplitChunk, (c+1)*kSplitChunk); chunk_row[c] = first row starting in it
   int *chunk_row = nullptr;
   int nchunks = 0;
