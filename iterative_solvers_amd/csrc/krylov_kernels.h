@@ -185,9 +185,13 @@ static __global__ __launch_bounds__(kVecThreads) void finalize_slab_kernel(const
 namespace mk {
 
 static int vec_blocks(int64_t n) {
-  int64_t want = (n / 2 + kVecThreads - 1) / kVecThreads;
+  // Every block of the NEXT kernel re-reads all partials of this one (prologue reduce), so the
+  // grid grows with the vector: at least 8 double2 per thread, one block per CU at the small end
+  // (1M rows: 256 blocks; with 2048 blocks the prologues moved 4x the bytes of the update itself).
+  int64_t want = (n / 2 + kVecThreads * 8 - 1) / (kVecThreads * 8);
   int64_t cap = (int64_t)ctx().num_cus * 8;
   if (cap > kSlabStride) cap = kSlabStride;
+  want = std::max<int64_t>(want, std::min<int64_t>(ctx().num_cus, (n / 2 + kVecThreads - 1) / kVecThreads));
   return (int)std::max<int64_t>(1, std::min(want, cap));
 }
 

@@ -95,6 +95,7 @@ struct mk_matrix {
   // stream kernel (fixed rows per chunk): lanes per row and LDS capacity in entries
   int stream_lanes = 0;
   int stream_cap = 0;
+  mutable int stream_bpc[3] = {0, 0, 0};   // resident blocks per CU of the stream kernel per MODE (occupancy query, cached)
   // column-index compression for the stream kernel: rows that share the same list of
   // (column - row) offsets share one table entry; the kernel then reads 2 B per row instead
   // of 4 B per entry.  pat == nullptr -> not compressed.

@@ -529,14 +529,15 @@ static int launch_stream_u(const mk_matrix *A, double alpha, const double *x, do
   const int64_t nchunks = (A->nrows + (kThreads / G) - 1) / (kThreads / G);
   // resident blocks per CU for this instantiation (registers + LDS), so the grid is one full wave of blocks
   static const int env_bpc = getenv("MK_STREAM_BPC") ? atoi(getenv("MK_STREAM_BPC")) : 0;
-  int per_cu = env_bpc;
-  if (per_cu <= 0) {
+  int per_cu = env_bpc > 0 ? env_bpc : A->stream_bpc[MODE];
+  if (per_cu <= 0) {   // first launch of this mode on this matrix: ask once, the query costs ~10 us of host time
     int occ = 0;
     hipError_t oe = hipErrorInvalidValue;
 #define MK_OCC_S(GG) case GG: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, spmv_stream_kernel<GG, MODE, U, COMP, NT>, kThreads, lds); break;
     switch (G) { MK_OCC_S(1) MK_OCC_S(2) MK_OCC_S(4) MK_OCC_S(8) MK_OCC_S(16) MK_OCC_S(32) MK_OCC_S(64) default: break; }
 #undef MK_OCC_S
     per_cu = (oe == hipSuccess && occ > 0) ? std::min(occ, 8) : 4;
+    A->stream_bpc[MODE] = per_cu;
   }
   int64_t blocks = std::min<int64_t>((nchunks + 7) / 8 * 8, (int64_t)c.num_cus * per_cu);
   blocks = std::max<int64_t>(8, blocks / 8 * 8);
