@@ -6,6 +6,9 @@
 #include <string.h>
 
 #include "mmio.h"
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 size_t get_multiple_of_align_size(size_t size) { return (size + align_size - 1) / align_size * align_size; }
 
@@ -24,14 +27,159 @@ void free_csr(SparseMatrixCSR *m) {
   m->values = NULL; m->column_indices = NULL; m->row_pointers = NULL;
 }
 
-/* Reference semantics kept (sparse_matrix.c:228-376):
+/* ---- entry parsing ---------------------------------------------------------------------
+ * Reference semantics kept (sparse_matrix.c:228-376):
  *  - coordinate files with real or pattern field only (:250-255);
  *  - indices turn 0-based (:297-299); pattern entries get 1.0 (:322,367);
  *  - symmetric: an off-diagonal (r,c,v) is followed at once by (c,r,v); the arrays are
  *    sized for 2*entries (:279-312);
- *  - nothing is filtered or merged: explicit zeros and duplicates stay (:372).
+ *  - nothing is filtered or merged: explicit zeros and duplicates stay (:372);
+ *  - exactly `entries` entries are read, whatever follows is ignored.
  * Differences: errors are returned, not exit()ed; a short file is an error instead of a
- * read past the buffer. */
+ * read past the buffer; and the text is parsed by all host cores (once the
+ * solve runs on the GPU, strtoul/strtod over the slurped file is the whole wall time). */
+
+/* the reference's loop: a whitespace-separated token stream, one thread */
+static int parse_serial(const char *path, char *text, unsigned int entries, int sym, int pat, SparseMatrixCOO *coo) {
+  unsigned int k = 0;
+  char *p = text, *q;
+  for (unsigned int i = 0; i < entries; i++) {
+    const unsigned long r = strtoul(p, &q, 10);
+    if (q == p) { fprintf(stderr, "%s: entry %u of %u missing\n", path, i + 1, entries); return 6; }
+    p = q;
+    const unsigned long c = strtoul(p, &q, 10);
+    if (q == p) { fprintf(stderr, "%s: entry %u truncated\n", path, i + 1); return 6; }
+    p = q;
+    double v = 1.0;
+    if (!pat) {
+      v = strtod(p, &q);
+      if (q == p) { fprintf(stderr, "%s: entry %u has no value\n", path, i + 1); return 6; }
+      p = q;
+    }
+    coo->rows[k] = (int)(r - 1);
+    coo->columns[k] = (int)(c - 1);
+    coo->values[k] = v;
+    k++;
+    if (sym && r != c) {
+      coo->rows[k] = (int)(c - 1);
+      coo->columns[k] = (int)(r - 1);
+      coo->values[k] = v;
+      k++;
+    }
+  }
+  coo->nnz = k;
+  return 0;
+}
+
+static int blank_to_eol(const char *p) {
+  while (*p == ' ' || *p == '\t' || *p == '\r') p++;
+  return *p == '\n' || *p == '\0';
+}
+
+/* One entry per line (what every Matrix Market writer produces): the text is cut at line
+ * ends into one piece per thread; pass 1 counts entries (and, for symmetric files, how many
+ * are off-diagonal) per piece, pass 2 parses each piece into its slice of the output.  Returns
+ * -1 when the text is not one-entry-per-line, and the caller falls back to parse_serial. */
+static int parse_parallel(char *text, size_t len, unsigned int entries, int sym, int pat, int nthreads, SparseMatrixCOO *coo) {
+  size_t *seg = (size_t *)malloc(sizeof(size_t) * (nthreads + 1));
+  long long *n_ent = (long long *)calloc(nthreads + 1, sizeof(long long));
+  long long *n_out = (long long *)calloc(nthreads + 1, sizeof(long long));
+  int bad = 0;
+  seg[0] = 0;
+  for (int t = 1; t < nthreads; t++) {
+    size_t s = len / nthreads * t;
+    if (s < seg[t - 1]) s = seg[t - 1];
+    while (s < len && text[s] != '\n') s++;
+    seg[t] = s < len ? s + 1 : len;
+  }
+  seg[nthreads] = len;
+#pragma omp parallel for num_threads(nthreads) schedule(static, 1) reduction(| : bad)
+  for (int t = 0; t < nthreads; t++) {
+    long long ne = 0, no = 0;
+    char *p = text + seg[t], *end = text + seg[t + 1], *q;
+    while (p < end) {
+      char *eol = (char *)memchr(p, '\n', (size_t)(end - p));
+      if (!eol) eol = end;
+      if (!blank_to_eol(p)) {
+        ne++;
+        if (sym) {
+          const unsigned long r = strtoul(p, &q, 10);
+          if (q == p || q > eol) { bad = 1; break; }
+          p = q;
+          const unsigned long c = strtoul(p, &q, 10);
+          if (q == p || q > eol) { bad = 1; break; }
+          no += (r != c) ? 2 : 1;
+        } else {
+          no++;
+        }
+      }
+      p = eol + 1;
+    }
+    n_ent[t + 1] = ne;
+    n_out[t + 1] = no;
+  }
+  if (!bad) {
+    for (int t = 0; t < nthreads; t++) { n_ent[t + 1] += n_ent[t]; }
+    if (n_ent[nthreads] < (long long)entries) bad = 1;     /* short, or entries span lines: let the token parser decide */
+  }
+  if (bad) { free(seg); free(n_ent); free(n_out); return -1; }
+  /* output offsets: only the first `entries` entries count, so pieces past that point are cut */
+  long long *out_off = (long long *)calloc(nthreads + 1, sizeof(long long));
+  int exact = 1;
+  for (int t = 0; t < nthreads; t++) {
+    if (n_ent[t + 1] > (long long)entries) exact = 0;      /* trailing extra lines: offsets of the cut piece unknown */
+    out_off[t + 1] = out_off[t] + n_out[t + 1];
+  }
+  if (!exact && sym) { free(seg); free(n_ent); free(n_out); free(out_off); return -1; }
+#pragma omp parallel for num_threads(nthreads) schedule(static, 1) reduction(| : bad)
+  for (int t = 0; t < nthreads; t++) {
+    long long i = n_ent[t];                       /* global index of this piece's first entry */
+    long long k = out_off[t];
+    char *p = text + seg[t], *end = text + seg[t + 1], *q;
+    while (p < end && i < (long long)entries) {
+      char *eol = (char *)memchr(p, '\n', (size_t)(end - p));
+      if (!eol) eol = end;
+      if (!blank_to_eol(p)) {
+        const unsigned long r = strtoul(p, &q, 10);
+        if (q == p || q > eol) { bad = 1; break; }
+        p = q;
+        const unsigned long c = strtoul(p, &q, 10);
+        if (q == p || q > eol) { bad = 1; break; }
+        p = q;
+        double v = 1.0;
+        if (!pat) {
+          v = strtod(p, &q);
+          if (q == p || q > eol) { bad = 1; break; }
+          p = q;
+        }
+        if (!blank_to_eol(p)) { bad = 1; break; }          /* more tokens on the line: not one entry per line */
+        coo->rows[k] = (int)(r - 1);
+        coo->columns[k] = (int)(c - 1);
+        coo->values[k] = v;
+        k++;
+        if (sym && r != c) {
+          coo->rows[k] = (int)(c - 1);
+          coo->columns[k] = (int)(r - 1);
+          coo->values[k] = v;
+          k++;
+        }
+        i++;
+      }
+      p = eol + 1;
+    }
+    n_out[t + 1] = k - out_off[t];                /* what was really written (the cut piece writes less) */
+  }
+  long long total = 0;
+  for (int t = 0; t < nthreads; t++) {
+    if (n_out[t + 1] != out_off[t + 1] - out_off[t] && n_ent[t + 1] <= (long long)entries) bad = 1;
+    total += n_out[t + 1];
+  }
+  free(seg); free(n_ent); free(n_out); free(out_off);
+  if (bad) return -1;
+  coo->nnz = (unsigned int)total;
+  return 0;
+}
+
 int fast_load_from_mtx_file(const char *path, SparseMatrixCOO *coo) {
   FILE *f = fopen(path, "r");
   if (!f) { fprintf(stderr, "Could not open file: %s \n", path); return 1; }
@@ -62,39 +210,27 @@ int fast_load_from_mtx_file(const char *path, SparseMatrixCOO *coo) {
   const size_t cap = (size_t)entries * (sym ? 2 : 1);
   coo->nrows = nrows;
   coo->ncolumns = ncols;
+  coo->nnz = 0;
   coo->rows = (int *)aalloc(cap * sizeof(int));
   coo->columns = (int *)aalloc(cap * sizeof(int));
   coo->values = (double *)aalloc(cap * sizeof(double));
   if (!coo->rows || !coo->columns || !coo->values) { free(text); free_coo(coo); return 5; }
-  unsigned int k = 0;
-  char *p = text, *q;
-  for (unsigned int i = 0; i < entries; i++) {
-    const unsigned long r = strtoul(p, &q, 10);
-    if (q == p) { fprintf(stderr, "%s: entry %u of %u missing\n", path, i + 1, entries); free(text); free_coo(coo); return 6; }
-    p = q;
-    const unsigned long c = strtoul(p, &q, 10);
-    if (q == p) { fprintf(stderr, "%s: entry %u truncated\n", path, i + 1); free(text); free_coo(coo); return 6; }
-    p = q;
-    double v = 1.0;
-    if (!pat) {
-      v = strtod(p, &q);
-      if (q == p) { fprintf(stderr, "%s: entry %u has no value\n", path, i + 1); free(text); free_coo(coo); return 6; }
-      p = q;
-    }
-    coo->rows[k] = (int)(r - 1);
-    coo->columns[k] = (int)(c - 1);
-    coo->values[k] = v;
-    k++;
-    if (sym && r != c) {
-      coo->rows[k] = (int)(c - 1);
-      coo->columns[k] = (int)(r - 1);
-      coo->values[k] = v;
-      k++;
-    }
-  }
-  coo->nnz = k;
+
+  int nthreads = 1;
+#ifdef _OPENMP
+  nthreads = omp_get_max_threads();
+#endif
+  const char *env_t = getenv("MK_PARSE_THREADS");
+  if (env_t) nthreads = atoi(env_t);
+  const char *env_min = getenv("MK_PARSE_MIN_ENTRIES");
+  const unsigned int min_entries = env_min ? (unsigned int)atol(env_min) : 200000u;
+  if (nthreads > 64) nthreads = 64;
+  int rc = -1;
+  if (nthreads > 1 && entries >= min_entries) rc = parse_parallel(text, got, entries, sym, pat, nthreads, coo);
+  if (rc == -1) rc = parse_serial(path, text, entries, sym, pat, coo);
   free(text);
-  return 0;
+  if (rc != 0) free_coo(coo);
+  return rc;
 }
 
 /* sparse_matrix.c:34-90: `m` values, one per line, of a Matrix Market array file (only the

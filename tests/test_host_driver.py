@@ -40,6 +40,82 @@ def test_loader_matches_reference_loader(name):
         assert np.array_equal(np.ctypeslib.as_array(m.values, (n,)).view(np.uint64), g["coo_vals"].view(np.uint64))
 
 
+def _load(L, path):
+    m = mk.COO()
+    rc = L.fast_load_from_mtx_file(str(path).encode(), C.byref(m))
+    if rc != 0:
+        return rc, None
+    n = m.nnz
+    take = lambda p, dt: np.ctypeslib.as_array(p, (n,)).astype(dt, copy=True) if n else np.empty(0, dt)
+    return 0, (m.nrows, m.ncolumns, take(m.rows, np.int32), take(m.columns, np.int32), take(m.values, np.float64))
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_parallel_parser_matches_reference_loader(name, monkeypatch):
+    # the multi-threaded entry parser, forced on for the small fixtures
+    L = _host()
+    monkeypatch.setenv("MK_PARSE_THREADS", "5")
+    monkeypatch.setenv("MK_PARSE_MIN_ENTRIES", "0")
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    rc, got = _load(L, os.path.join(GOLDEN, name + ".mtx"))
+    assert rc == 0
+    assert np.array_equal(got[2], g["coo_rows"]) and np.array_equal(got[3], g["coo_cols"])
+    assert np.array_equal(got[4].view(np.uint64), g["coo_vals"].view(np.uint64))
+
+
+@pytest.mark.parametrize("field,sym", [("real", "general"), ("real", "symmetric"), ("pattern", "general"), ("pattern", "symmetric")])
+def test_parallel_parser_equals_serial_parser(tmp_path, monkeypatch, field, sym):
+    L = _host()
+    rng = np.random.default_rng(11)
+    n, m = 5000, 60000
+    r = rng.integers(1, n + 1, m)
+    c = rng.integers(1, n + 1, m)
+    if sym == "symmetric":
+        r, c = np.maximum(r, c), np.minimum(r, c)
+    v = rng.normal(size=m) * 10.0 ** rng.integers(-200, 200, m)
+    p = tmp_path / "big.mtx"
+    with open(p, "w") as f:
+        f.write(f"%%MatrixMarket matrix coordinate {field} {sym}\n% comment line\n{n} {n} {m}\n")
+        for i in range(m):
+            pad = " " * int(rng.integers(1, 4))
+            f.write(f"{r[i]}{pad}{c[i]}\n" if field == "pattern" else f"{r[i]}{pad}{c[i]}\t{float(v[i])!r}\r\n" if i % 97 == 0 else f"{r[i]} {c[i]} {v[i]:.17g}\n")
+            if i % 5000 == 0:
+                f.write("\n")                       # blank lines are legal
+    monkeypatch.setenv("MK_PARSE_MIN_ENTRIES", "0")
+    monkeypatch.setenv("MK_PARSE_THREADS", "1")
+    rc1, a = _load(L, p)
+    for t in ("2", "7", "16"):
+        monkeypatch.setenv("MK_PARSE_THREADS", t)
+        rc2, b = _load(L, p)
+        assert rc1 == 0 and rc2 == 0 and a[:2] == b[:2]
+        for u, w in zip(a[2:], b[2:]):
+            assert np.array_equal(u.view(np.uint8), w.view(np.uint8))
+    if oracle.have_ref():                         # and the serial parser equals the reference's loader
+        rr = oracle.ref_load_mtx(str(p))
+        assert np.array_equal(rr[2], a[2]) and np.array_equal(rr[3], a[3]) and np.array_equal(rr[4].view(np.uint64), a[4].view(np.uint64))
+
+
+def test_parallel_parser_falls_back_on_odd_layouts(tmp_path, monkeypatch):
+    L = _host()
+    monkeypatch.setenv("MK_PARSE_MIN_ENTRIES", "0")
+    monkeypatch.setenv("MK_PARSE_THREADS", "4")
+    # entries spread over several lines / several entries per line: legal token stream for the reference
+    p = tmp_path / "tokens.mtx"
+    p.write_text("%%MatrixMarket matrix coordinate real general\n3 3 4\n1 1\n1.5 2 2 2.5\n3 3 3.5 1\n3 -1\n")
+    rc, got = _load(L, p)
+    assert rc == 0 and got[2].tolist() == [0, 1, 2, 0] and got[3].tolist() == [0, 1, 2, 2] and got[4].tolist() == [1.5, 2.5, 3.5, -1.0]
+    # more lines than the header announces: the first `entries` count, the rest is ignored
+    p = tmp_path / "extra.mtx"
+    p.write_text("%%MatrixMarket matrix coordinate real general\n3 3 2\n1 1 1.0\n2 2 2.0\n3 3 3.0\n3 1 4.0\n")
+    rc, got = _load(L, p)
+    assert rc == 0 and got[4].tolist() == [1.0, 2.0]
+    # fewer lines than announced: an error, not a crash
+    p = tmp_path / "short.mtx"
+    p.write_text("%%MatrixMarket matrix coordinate real general\n3 3 5\n1 1 1.0\n2 2 2.0\n")
+    rc, got = _load(L, p)
+    assert rc != 0
+
+
 def test_loader_errors_are_returned_not_fatal(tmp_path):
     L = _host()
     m = mk.COO()
