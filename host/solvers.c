@@ -46,11 +46,12 @@ static void usage(const char *argv0) {
   printf("                           50 - PCG\n");
   printf("                           51 - PCG + diagonal scaling\n");
   printf("                           70 - Jacobi iteration\n");
+  printf("  -cache                 : keep <matrix.mtx>.mkcsr (binary CSR) and load it instead of the text when present\n");
   printf("  -print_system          : write the assembled CSR back to IJ.out.A as text\n\n");
 }
 
 int main(int argc, char *argv[]) {
-  int maxit = 1000, prnt_info = 2, precond_log = 1, niter = 1, solver_id = 0, print_system = 0, dev = 0, comp_id = 0;
+  int maxit = 1000, prnt_info = 2, precond_log = 1, niter = 1, solver_id = 0, print_system = 0, dev = 0, comp_id = 0, use_cache = 0;
   double tol = 1e-6;
   const char *mtx = NULL, *bfile = NULL, *xfile = NULL, *pow_file = NULL;
   (void)precond_log; (void)comp_id; (void)pow_file;
@@ -71,6 +72,7 @@ int main(int argc, char *argv[]) {
     else if (!strcmp(a, "-x") && has) { xfile = argv[i + 1]; i += 2; }
     else if (!strcmp(a, "-dev") && has) { dev = atoi(argv[i + 1]); i += 2; }
     else if (!strcmp(a, "-print_system")) { print_system = 1; i += 1; }
+    else if (!strcmp(a, "-cache")) { use_cache = 1; i += 1; }
     else if (!strcmp(a, "-help")) { usage(argv[0]); return 0; }
     else i += 1;                                                      /* unknown flags are skipped (:149-151) */
   }
@@ -83,20 +85,38 @@ int main(int argc, char *argv[]) {
 
   CK(mk_init(dev));                                                   /* HYPRE_Init (:79) */
 
-  SparseMatrixCOO coo;
-  double t0 = now_s();
-  if (fast_load_from_mtx_file(mtx, &coo) != 0) return 1;              /* :196 */
-  double t1 = now_s();
-  if (coo.nrows != coo.ncolumns) { fprintf(stderr, "matrix is %u x %u: a square system is required\n", coo.nrows, coo.ncolumns); return 1; }
-  /* the reference sorts on the host (:198) and hands slices to HYPRE (:330); here the
-   * unsorted COO goes to the device, which sorts, converts and keeps the CSR */
   mk_matrix *A = NULL;
-  CK(mk_matrix_from_coo(&coo, &A));                                   /* :289-374 */
-  double t2 = now_s();
-  fprintf(stderr, "Finish reading and sorting of COO data\n");        /* :212 */
-  fprintf(stderr, "Dataset reading time: %lg msec, device assembly: %lg msec\n", (t1 - t0) * 1e3, (t2 - t1) * 1e3);
-  const unsigned int n = coo.nrows;
-  free_coo(&coo);                                                     /* :376-378 */
+  unsigned int n = 0;
+  char cache_path[4096];
+  snprintf(cache_path, sizeof cache_path, "%s.mkcsr", mtx);
+  SparseMatrixCSR cached;
+  double t0 = now_s();
+  if (use_cache && read_csr_cache(cache_path, &cached) == 0) {
+    if (cached.nrows != cached.ncolumns) { fprintf(stderr, "matrix is %u x %u: a square system is required\n", cached.nrows, cached.ncolumns); return 1; }
+    CK(mk_matrix_from_csr(&cached, &A));
+    n = cached.nrows;
+    free_csr(&cached);
+    fprintf(stderr, "Loaded binary CSR cache %s: %lg msec\n", cache_path, (now_s() - t0) * 1e3);
+  } else {
+    SparseMatrixCOO coo;
+    if (fast_load_from_mtx_file(mtx, &coo) != 0) return 1;              /* :196 */
+    double t1 = now_s();
+    if (coo.nrows != coo.ncolumns) { fprintf(stderr, "matrix is %u x %u: a square system is required\n", coo.nrows, coo.ncolumns); return 1; }
+    /* the reference sorts on the host (:198) and hands slices to HYPRE (:330); here the
+     * unsorted COO goes to the device, which sorts, converts and keeps the CSR */
+    CK(mk_matrix_from_coo(&coo, &A));                                   /* :289-374 */
+    double t2 = now_s();
+    fprintf(stderr, "Finish reading and sorting of COO data\n");        /* :212 */
+    fprintf(stderr, "Dataset reading time: %lg msec, device assembly: %lg msec\n", (t1 - t0) * 1e3, (t2 - t1) * 1e3);
+    n = coo.nrows;
+    free_coo(&coo);                                                     /* :376-378 */
+    if (use_cache) {
+      SparseMatrixCSR csr;
+      CK(mk_matrix_get_csr(A, &csr));
+      if (write_csr_cache(cache_path, &csr) != 0) fprintf(stderr, "could not write %s\n", cache_path);
+      free_csr(&csr);
+    }
+  }
 
   mk_vector *b = NULL, *x = NULL;
   CK(mk_vector_create(n, &b));

@@ -305,3 +305,72 @@ int write_stencil_mtx(const char *path, int kind, int nx, int ny, int nz) {
   fclose(f);
   return 0;
 }
+
+/* ---- binary CSR cache: the converted matrix beside the .mtx, so that a second
+ * run skips both the text parse and the sort.  Layout: 64-byte header, then row_pointers
+ * (int32[nrows+1]), column_indices (int32[nnz]), values (f64[nnz]), each padded to 64 bytes.
+ * No reference counterpart. */
+typedef struct {
+  char magic[8];            /* "MKCSR01\0" */
+  unsigned int nrows, ncolumns, nnz, endian_mark;
+  unsigned long long checksum;   /* sum of all row pointers and column indices, wrap-around */
+  char pad[32];
+} csr_cache_header;
+
+static unsigned long long csr_checksum(const SparseMatrixCSR *m) {
+  unsigned long long s = 0;
+  for (unsigned int i = 0; i <= m->nrows; i++) s += (unsigned int)m->row_pointers[i];
+  for (unsigned int k = 0; k < m->nnz; k++) s += (unsigned int)m->column_indices[k];
+  return s;
+}
+
+static int write_padded(FILE *f, const void *p, size_t bytes) {
+  static const char zeros[64] = {0};
+  if (bytes && fwrite(p, 1, bytes, f) != bytes) return 1;
+  const size_t padn = (64 - bytes % 64) % 64;
+  return padn && fwrite(zeros, 1, padn, f) != padn;
+}
+
+int write_csr_cache(const char *path, const SparseMatrixCSR *m) {
+  FILE *f = fopen(path, "wb");
+  if (!f) return 1;
+  csr_cache_header h;
+  memset(&h, 0, sizeof h);
+  memcpy(h.magic, "MKCSR01", 8);
+  h.nrows = m->nrows; h.ncolumns = m->ncolumns; h.nnz = m->nnz; h.endian_mark = 0x01020304u;
+  h.checksum = csr_checksum(m);
+  int bad = fwrite(&h, sizeof h, 1, f) != 1;
+  bad = bad || write_padded(f, m->row_pointers, ((size_t)m->nrows + 1) * sizeof(int));
+  bad = bad || write_padded(f, m->column_indices, (size_t)m->nnz * sizeof(int));
+  bad = bad || write_padded(f, m->values, (size_t)m->nnz * sizeof(double));
+  bad = (fclose(f) != 0) || bad;
+  if (bad) remove(path);
+  return bad;
+}
+
+static int read_padded(FILE *f, void *p, size_t bytes) {
+  if (bytes && fread(p, 1, bytes, f) != bytes) return 1;
+  const long padn = (long)((64 - bytes % 64) % 64);
+  return padn && fseek(f, padn, SEEK_CUR) != 0;
+}
+
+/* returns 0 and fills *m (aligned_alloc'ed arrays), or non-zero when the file is absent, short,
+ * from another byte order, or fails its checksum */
+int read_csr_cache(const char *path, SparseMatrixCSR *m) {
+  FILE *f = fopen(path, "rb");
+  if (!f) return 1;
+  csr_cache_header h;
+  if (fread(&h, sizeof h, 1, f) != 1 || memcmp(h.magic, "MKCSR01", 8) != 0 || h.endian_mark != 0x01020304u) { fclose(f); return 2; }
+  m->nrows = h.nrows; m->ncolumns = h.ncolumns; m->nnz = h.nnz;
+  m->row_pointers = (int *)aalloc(((size_t)h.nrows + 1) * sizeof(int));
+  m->column_indices = (int *)aalloc((size_t)h.nnz * sizeof(int));
+  m->values = (double *)aalloc((size_t)h.nnz * sizeof(double));
+  int bad = !m->row_pointers || !m->column_indices || !m->values;
+  bad = bad || read_padded(f, m->row_pointers, ((size_t)h.nrows + 1) * sizeof(int));
+  bad = bad || read_padded(f, m->column_indices, (size_t)h.nnz * sizeof(int));
+  bad = bad || read_padded(f, m->values, (size_t)h.nnz * sizeof(double));
+  fclose(f);
+  if (!bad) bad = (m->row_pointers[0] != 0) || ((unsigned int)m->row_pointers[h.nrows] != h.nnz) || (csr_checksum(m) != h.checksum);
+  if (bad) { free_csr(m); return 3; }
+  return 0;
+}

@@ -25,6 +25,9 @@ int convert_coo_to_csr(const SparseMatrixCOO *coo_matrix, SparseMatrixCSR *csr_m
 void free_coo(SparseMatrixCOO *m);
 void free_csr(SparseMatrixCSR *m);
 size_t get_multiple_of_align_size(size_t size);
+/* binary CSR cache beside the .mtx (extension) */
+int write_csr_cache(const char *path, const SparseMatrixCSR *m);
+int read_csr_cache(const char *path, SparseMatrixCSR *m);
 int write_stencil_mtx(const char *path, int kind, int nx, int ny, int nz);   /* synthetic test input */
 #ifdef __cplusplus
 }

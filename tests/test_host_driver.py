@@ -116,6 +116,29 @@ def test_parallel_parser_falls_back_on_odd_layouts(tmp_path, monkeypatch):
     assert rc != 0
 
 
+def test_csr_cache_round_trip(tmp_path):
+    L = _host()
+    L.write_csr_cache.argtypes = [C.c_char_p, C.POINTER(mk.CSR)]
+    L.read_csr_cache.argtypes = [C.c_char_p, C.POINTER(mk.CSR)]
+    g = np.load(os.path.join(GOLDEN, "random_70k.npz"))
+    rp, ci, v = (np.ascontiguousarray(g[k]) for k in ("csr_rowptr", "csr_col", "csr_val"))
+    m = mk.CSR(v.ctypes.data_as(C.POINTER(C.c_double)), ci.ctypes.data_as(C.POINTER(C.c_int)),
+               rp.ctypes.data_as(C.POINTER(C.c_int)), int(g["nrows"]), int(g["ncols"]), ci.size)
+    path = str(tmp_path / "a.mkcsr").encode()
+    assert L.write_csr_cache(path, C.byref(m)) == 0
+    r = mk.CSR()
+    assert L.read_csr_cache(path, C.byref(r)) == 0
+    assert (r.nrows, r.ncolumns, r.nnz) == (m.nrows, m.ncolumns, m.nnz)
+    assert np.array_equal(np.ctypeslib.as_array(r.row_pointers, (r.nrows + 1,)), rp)
+    assert np.array_equal(np.ctypeslib.as_array(r.column_indices, (r.nnz,)), ci)
+    assert np.array_equal(np.ctypeslib.as_array(r.values, (r.nnz,)).view(np.uint64), v.view(np.uint64))
+    raw = bytearray(open(path, "rb").read())
+    raw[64 + 40] ^= 1                                     # flip one bit of a row pointer
+    open(path, "wb").write(raw)
+    assert L.read_csr_cache(path, C.byref(r)) != 0        # checksum catches it
+    assert L.read_csr_cache(str(tmp_path / "absent").encode(), C.byref(r)) != 0
+
+
 def test_loader_errors_are_returned_not_fatal(tmp_path):
     L = _host()
     m = mk.COO()
@@ -162,6 +185,21 @@ def test_driver_pcg_output_lines(tmp_path, solver, precond):
     o = oracle.pcg(rp, ci, v, np.ones(rp.size - 1), tol=1e-8, precond=precond, maxit=500)
     assert abs(it - o["iterations"]) <= 2 and nrm < 1e-8
     assert "Finish reading and sorting of COO data" in out.stderr
+
+
+@pytest.mark.gpu
+def test_driver_binary_cache(tmp_path):
+    mtx = tmp_path / "poisson.mtx"
+    _write_poisson(mtx, 40, 40, shuffle_seed=2)
+    outs = []
+    for _ in range(2):
+        o = subprocess.run([os.path.join(HOST, "solver"), "-solver", "50", "-mtx", str(mtx), "-cache", "-tol", "1e-9"],
+                           capture_output=True, text=True, timeout=120)
+        assert o.returncode == 0, o.stderr
+        outs.append(o)
+    assert os.path.exists(str(mtx) + ".mkcsr") and "Loaded binary CSR cache" in outs[1].stderr
+    pick = lambda o: re.findall(r"^(Iterations = \d+|Final Relative Residual Norm = \S+)$", o.stdout, re.M)
+    assert pick(outs[0]) == pick(outs[1]) and len(pick(outs[0])) == 2
 
 
 @pytest.mark.gpu
