@@ -105,6 +105,8 @@ typedef struct {
   int64_t long_rows;       /* rows of >= 2048 entries (always split over chunks by MK_SPMV_SPLIT) */
   int64_t index_patterns;  /* > 0: column indices are served from a table of that many (column - row) patterns
                               (lossless; the stream kernel then reads 2 B per row instead of 4 B per entry) */
+  int64_t value_patterns;  /* > 0: the rows of a pattern also share their values bit for bit (constant-coefficient
+                              operators); MK_SPMV_PATTERN then serves offsets AND values from the table */
 } mk_matrix_info;
 int mk_matrix_get_info(const mk_matrix *A, mk_matrix_info *info);
 
@@ -112,8 +114,10 @@ typedef enum {
   MK_SPMV_AUTO = 0,
   MK_SPMV_VECTOR = 1,      /* 2^k lanes per row, k from the mean row length (k=6: wavefront per row) */
   MK_SPMV_STREAM = 2,      /* regular rows: 256/G consecutive rows per chunk staged through LDS, one pass per row group */
-  MK_SPMV_SPLIT = 3        /* skewed rows: nnz-balanced chunks (merge-path style), products staged in LDS, rows split
+  MK_SPMV_SPLIT = 3,       /* skewed rows: nnz-balanced chunks (merge-path style), products staged in LDS, rows split
                               inside and across chunks, carries folded in a fixed order by a second small kernel */
+  MK_SPMV_PATTERN = 4      /* rows drawn from a small table of (offsets, values) patterns: one lane per row, 2 B of
+                              matrix data per row; only when mk_matrix_info.value_patterns > 0 */
 } mk_spmv_kernel;
 /* override the selector (lanes_per_row: 0 = keep, else 1..64 power of two) */
 int mk_matrix_set_spmv_kernel(mk_matrix *A, int kernel, int lanes_per_row);

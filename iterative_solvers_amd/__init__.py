@@ -34,10 +34,10 @@ class MatrixInfo(C.Structure):
     _fields_ = [("nrows", C.c_int64), ("ncols", C.c_int64), ("nnz", C.c_int64),
                 ("max_row_len", C.c_int32), ("min_row_len", C.c_int32), ("mean_row_len", C.c_double),
                 ("hist", C.c_int64 * 16), ("kernel", C.c_int32), ("lanes_per_row", C.c_int32),
-                ("long_rows", C.c_int64), ("index_patterns", C.c_int64)]
+                ("long_rows", C.c_int64), ("index_patterns", C.c_int64), ("value_patterns", C.c_int64)]
 
 
-SPMV_AUTO, SPMV_VECTOR, SPMV_STREAM, SPMV_SPLIT = 0, 1, 2, 3
+SPMV_AUTO, SPMV_VECTOR, SPMV_STREAM, SPMV_SPLIT, SPMV_PATTERN = 0, 1, 2, 3, 4
 PRECOND_NONE, PRECOND_JACOBI = 0, 1
 
 # every symbol include/mk_krylov.h declares (tests check the library exports all of them)

@@ -95,12 +95,18 @@ struct mk_matrix {
   // stream kernel (fixed rows per chunk): lanes per row and LDS capacity in entries
   int stream_lanes = 0;
   int stream_cap = 0;
-  mutable int stream_bpc[3] = {0, 0, 0};   // resident blocks per CU of the stream kernel per MODE (occupancy query, cached)
+  mutable int stream_bpc[3] = {0, 0, 0};
+  mutable int pattern_bpc[3] = {0, 0, 0};   // resident blocks per CU of the stream kernel per MODE (occupancy query, cached)
   // column-index compression for the stream kernel: rows that share the same list of
   // (column - row) offsets share one table entry; the kernel then reads 2 B per row instead
   // of 4 B per entry.  pat == nullptr -> not compressed.
   unsigned short *pat = nullptr;   // pattern id per row
   int *ptab = nullptr;             // npat x (pml+1) ints: length, offsets
+  double *vtab = nullptr;          // npat x pml doubles when the rows of a pattern also share their values
+                                   // (pattern kernel: neither col[] nor val[] nor rowptr[] is read)
+  int *otab8 = nullptr;            // pattern kernel's padded copies of ptab / vtab (row stride p8 + 8 ints, p8 doubles)
+  double *vtab8 = nullptr;
+  int p8 = 0;
   int npat = 0, pml = 0;
   int max_off = 0;                 // largest |column - row| over all patterns
   // split kernel: chunk c covers entries [c*kSplitChunk, (c+1)*kSplitChunk); chunk_row[c] = first row starting in it

@@ -61,24 +61,41 @@ __global__ void diag_inverse_kernel(int64_t nrows, const int *__restrict__ rowpt
 // Lossless: the product reads exactly the same (column, value) pairs in the same order.
 constexpr int kPatSlots = 1 << 16;
 constexpr int kPatMaxLen = 32;      // rows longer than this are not worth a table entry
+constexpr int kPatMaxProbes = 512;
 constexpr int kPatMaxInts = 8192;   // table must fit 32 KB of LDS beside the value stage
 
-__device__ __forceinline__ unsigned long long pat_hash(int64_t row, const int *__restrict__ rowptr, const int *__restrict__ col) {
+// VAL: the row's values (bit patterns) are part of the key, so rows that share a table entry carry
+// the same coefficients as well (constant-coefficient stencils, banded Toeplitz-like operators)
+template <bool VAL>
+__device__ __forceinline__ unsigned long long pat_hash(int64_t row, const int *__restrict__ rowptr, const int *__restrict__ col,
+                                                       const double *__restrict__ val) {
   unsigned long long h = 0xCBF29CE484222325ULL;
   const int b = rowptr[row], e = rowptr[row + 1];
   h = (h ^ (unsigned long long)(unsigned)(e - b)) * 0x100000001B3ULL;
   for (int k = b; k < e; k++) h = (h ^ (unsigned long long)(unsigned)(col[k] - (int)row)) * 0x100000001B3ULL;
+  if (VAL)
+    for (int k = b; k < e; k++) {
+      const unsigned long long bits = (unsigned long long)__double_as_longlong(val[k]);
+      h = (h ^ (bits & 0xffffffffULL)) * 0x100000001B3ULL;
+      h = (h ^ (bits >> 32)) * 0x100000001B3ULL;
+    }
   h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ULL; h ^= h >> 32;
   return h | 1ULL;   // 0 marks an empty slot
 }
 
+template <bool VAL>
 __global__ void pat_insert_kernel(int64_t nrows, const int *__restrict__ rowptr, const int *__restrict__ col,
-                                  unsigned long long *__restrict__ keys, int *__restrict__ slot_of_row, int *__restrict__ fail) {
+                                  const double *__restrict__ val, unsigned long long *__restrict__ keys,
+                                  int *__restrict__ slot_of_row, int *__restrict__ fail) {
   for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += (int64_t)gridDim.x * blockDim.x) {
-    const unsigned long long h = pat_hash(r, rowptr, col);
+    const unsigned long long h = pat_hash<VAL>(r, rowptr, col, val);
     unsigned s = (unsigned)(h >> 40) & (kPatSlots - 1);
+    // a usable table holds at most kPatMaxInts/2 = 4096 patterns (6 % of the slots), so a long probe
+    // sequence means "too many patterns": give up at once, and let every other row give up with it
+    // (a matrix of all-distinct rows would otherwise scan the full table once per row)
+    if (__hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
     int probes = 0;
-    for (; probes < kPatSlots; probes++) {
+    for (; probes < kPatMaxProbes; probes++) {
       // look before the atomic: with a few dozen patterns shared by millions of rows nearly every
       // row finds its key already there (134M contended CAS on 27 words took 0.85 s)
       unsigned long long old = __hip_atomic_load(&keys[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -86,7 +103,7 @@ __global__ void pat_insert_kernel(int64_t nrows, const int *__restrict__ rowptr,
       if (old == 0ULL || old == h) break;
       s = (s + 1) & (kPatSlots - 1);
     }
-    if (probes == kPatSlots) *fail = 1;
+    if (probes == kPatMaxProbes) { *fail = 1; return; }
     slot_of_row[r] = (int)s;
   }
 }
@@ -115,9 +132,11 @@ __global__ __launch_bounds__(1024) void pat_compact_kernel(const unsigned long l
   if (threadIdx.x == 1023) *npat = sums[1023];
 }
 
+template <bool VAL>
 __global__ void pat_assign_kernel(int64_t nrows, const int *__restrict__ rowptr, const int *__restrict__ col,
-                                  const int *__restrict__ slot_of_row, const int *__restrict__ id_of_slot,
-                                  unsigned short *__restrict__ pat, int *__restrict__ ptab, int pml, int *__restrict__ written) {
+                                  const double *__restrict__ val, const int *__restrict__ slot_of_row,
+                                  const int *__restrict__ id_of_slot, unsigned short *__restrict__ pat, int *__restrict__ ptab,
+                                  double *__restrict__ vtab, int pml, int *__restrict__ written) {
   for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += (int64_t)gridDim.x * blockDim.x) {
     const int id = id_of_slot[slot_of_row[r]];
     pat[r] = (unsigned short)id;
@@ -127,25 +146,42 @@ __global__ void pat_assign_kernel(int64_t nrows, const int *__restrict__ rowptr,
       t[0] = e - b;
       for (int k = b; k < e; k++) t[1 + k - b] = col[k] - (int)r;
       for (int k = e - b; k < pml; k++) t[1 + k] = 0;
+      if (VAL) {
+        double *tv = vtab + (size_t)id * pml;
+        for (int k = b; k < e; k++) tv[k - b] = val[k];
+        for (int k = e - b; k < pml; k++) tv[k] = 0.0;
+      }
     }
   }
 }
 
 // hash collisions would silently change the matrix: compare every row with its table entry
+template <bool VAL>
 __global__ void pat_verify_kernel(int64_t nrows, const int *__restrict__ rowptr, const int *__restrict__ col,
-                                  const unsigned short *__restrict__ pat, const int *__restrict__ ptab, int pml, int *__restrict__ fail) {
+                                  const double *__restrict__ val, const unsigned short *__restrict__ pat,
+                                  const int *__restrict__ ptab, const double *__restrict__ vtab, int pml, int *__restrict__ fail) {
   for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += (int64_t)gridDim.x * blockDim.x) {
     const int *t = ptab + (size_t)pat[r] * (pml + 1);
     const int b = rowptr[r], e = rowptr[r + 1];
     bool ok = (t[0] == e - b);
     for (int k = b; ok && k < e; k++) ok = (t[1 + k - b] == col[k] - (int)r);
+    if (VAL) {
+      const double *tv = vtab + (size_t)pat[r] * pml;
+      for (int k = b; ok && k < e; k++) ok = (__double_as_longlong(tv[k - b]) == __double_as_longlong(val[k]));   // bits, not ==: -0.0 and NaNs too
+    }
     if (!ok) *fail = 1;
   }
 }
 
-static int try_compress_indices(mk_matrix *A) {
-  static const int disabled = getenv("MK_NO_INDEX_COMPRESSION") ? atoi(getenv("MK_NO_INDEX_COMPRESSION")) : 0;
-  if (disabled || A->pat || A->nrows == 0 || A->info.max_row_len > kPatMaxLen || A->info.max_row_len < 1) return MK_OK;
+constexpr int kPatMaxValBytes = 32768;
+constexpr int kPatternChunkRows = 2 * kThreads;   // pattern kernel: rows per chunk   // value table (doubles) beside the offset table in LDS
+
+// with_values: key = (offsets, values); the pattern kernel then needs neither col[] nor val[] nor rowptr[]
+template <bool VAL>
+static int try_compress(mk_matrix *A) {
+  static const int no_idx = getenv("MK_NO_INDEX_COMPRESSION") ? atoi(getenv("MK_NO_INDEX_COMPRESSION")) : 0;
+  static const int no_val = getenv("MK_NO_VALUE_COMPRESSION") ? atoi(getenv("MK_NO_VALUE_COMPRESSION")) : 0;
+  if (no_idx || (VAL && no_val) || A->pat || A->nrows == 0 || A->info.max_row_len > kPatMaxLen || A->info.max_row_len < 1) return MK_OK;
   Context &c = ctx();
   const int pml = A->info.max_row_len;
   unsigned long long *keys = nullptr;
@@ -157,25 +193,30 @@ static int try_compress_indices(mk_matrix *A) {
   MK_HIP(hipMemsetAsync(keys, 0, sizeof(unsigned long long) * kPatSlots, c.stream));
   MK_HIP(hipMemsetAsync(flags, 0, sizeof(int) * 2, c.stream));
   const int blocks = (int)std::min<int64_t>((A->nrows + 255) / 256, 4096);
-  hipLaunchKernelGGL(pat_insert_kernel, dim3(blocks), dim3(256), 0, c.stream, A->nrows, A->rowptr, A->col, keys, slot, flags);
+  hipLaunchKernelGGL(pat_insert_kernel<VAL>, dim3(blocks), dim3(256), 0, c.stream, A->nrows, A->rowptr, A->col, A->val, keys, slot, flags);
   hipLaunchKernelGGL(pat_compact_kernel, dim3(1), dim3(1024), 0, c.stream, keys, ids, flags + 1);
   int h[2] = {0, 0};
   MK_HIP(hipMemcpyAsync(h, flags, sizeof(h), hipMemcpyDeviceToHost, c.stream));
   MK_HIP(hipStreamSynchronize(c.stream));
   bool ok = (h[0] == 0) && h[1] >= 1 && h[1] <= 65535 && (int64_t)h[1] * (pml + 1) <= kPatMaxInts;
+  // a value table pays only when many rows share an entry (every block loads the whole table)
+  if (VAL) ok = ok && (int64_t)h[1] * pml * 8 <= kPatMaxValBytes && (int64_t)h[1] <= std::max<int64_t>(32, A->nrows / 16);
   if (ok) {
     const int npat = h[1];
     MK_TRY(dev_alloc(&A->pat, (size_t)A->nrows));
     MK_TRY(dev_alloc(&A->ptab, (size_t)npat * (pml + 1)));
+    if (VAL) MK_TRY(dev_alloc(&A->vtab, (size_t)npat * pml));
     MK_TRY(dev_alloc(&written, (size_t)npat));
     MK_HIP(hipMemsetAsync(written, 0, sizeof(int) * npat, c.stream));
-    hipLaunchKernelGGL(pat_assign_kernel, dim3(blocks), dim3(256), 0, c.stream, A->nrows, A->rowptr, A->col, slot, ids, A->pat, A->ptab, pml, written);
-    hipLaunchKernelGGL(pat_verify_kernel, dim3(blocks), dim3(256), 0, c.stream, A->nrows, A->rowptr, A->col, A->pat, A->ptab, pml, flags);
+    hipLaunchKernelGGL(pat_assign_kernel<VAL>, dim3(blocks), dim3(256), 0, c.stream, A->nrows, A->rowptr, A->col, A->val, slot, ids,
+                       A->pat, A->ptab, A->vtab, pml, written);
+    hipLaunchKernelGGL(pat_verify_kernel<VAL>, dim3(blocks), dim3(256), 0, c.stream, A->nrows, A->rowptr, A->col, A->val, A->pat,
+                       A->ptab, A->vtab, pml, flags);
     MK_HIP(hipMemcpyAsync(h, flags, sizeof(int), hipMemcpyDeviceToHost, c.stream));
     MK_HIP(hipStreamSynchronize(c.stream));
     if (h[0] != 0) {   // collision: keep the plain CSR path
-      dev_free(A->pat); dev_free(A->ptab);
-      A->pat = nullptr; A->ptab = nullptr;
+      dev_free(A->pat); dev_free(A->ptab); dev_free(A->vtab);
+      A->pat = nullptr; A->ptab = nullptr; A->vtab = nullptr;
     } else {
       A->npat = npat; A->pml = pml;
       std::vector<int> tab((size_t)npat * (pml + 1));
@@ -185,6 +226,27 @@ static int try_compress_indices(mk_matrix *A) {
       for (int q = 0; q < npat; q++)
         for (int k = 0; k < tab[(size_t)q * (pml + 1)]; k++) mo = std::max(mo, std::abs(tab[(size_t)q * (pml + 1) + 1 + k]));
       A->max_off = mo;
+      if (VAL) {   // padded copies for the pattern kernel (layout: see spmv_pattern_kernel)
+        const int P8 = (pml + 7) & ~7, SP = P8 + 8;
+        std::vector<double> vals((size_t)npat * pml), v8((size_t)npat * P8, 0.0);
+        std::vector<int> o8((size_t)npat * SP, 0);
+        MK_HIP(hipMemcpyAsync(vals.data(), A->vtab, sizeof(double) * vals.size(), hipMemcpyDeviceToHost, c.stream));
+        MK_HIP(hipStreamSynchronize(c.stream));
+        for (int q = 0; q < npat; q++) {
+          const int len = tab[(size_t)q * (pml + 1)];
+          o8[(size_t)q * SP] = len;
+          for (int k = 0; k < len; k++) {
+            o8[(size_t)q * SP + 8 + k] = tab[(size_t)q * (pml + 1) + 1 + k];
+            v8[(size_t)q * P8 + k] = vals[(size_t)q * pml + k];
+          }
+        }
+        MK_TRY(dev_alloc(&A->otab8, o8.size()));
+        MK_TRY(dev_alloc(&A->vtab8, v8.size()));
+        MK_HIP(hipMemcpyAsync(A->otab8, o8.data(), sizeof(int) * o8.size(), hipMemcpyHostToDevice, c.stream));
+        MK_HIP(hipMemcpyAsync(A->vtab8, v8.data(), sizeof(double) * v8.size(), hipMemcpyHostToDevice, c.stream));
+        MK_HIP(hipStreamSynchronize(c.stream));
+        A->p8 = P8;
+      }
     }
   }
   dev_free(keys); dev_free(slot); dev_free(ids); dev_free(flags); dev_free(written);
@@ -225,6 +287,7 @@ int analyse_matrix(mk_matrix *A) {
   A->stream_cap = (int)((std::max<int64_t>(64, (int64_t)(kThreads / sl) * I.max_row_len) + 3) & ~(int64_t)3);
   const bool stream_ok = A->stream_cap <= kStreamMaxCap;
   // regular rows -> stream; rows too long for a row-aligned LDS chunk (skewed / power law) -> split
+  const bool was_auto = (A->kernel == MK_SPMV_AUTO);
   if (A->kernel == MK_SPMV_AUTO) A->kernel = stream_ok ? MK_SPMV_STREAM : MK_SPMV_SPLIT;
   if (A->kernel == MK_SPMV_STREAM && !stream_ok) A->kernel = MK_SPMV_SPLIT;
   int64_t longr = 0;
@@ -233,8 +296,14 @@ int analyse_matrix(mk_matrix *A) {
   I.kernel = A->kernel;
   I.lanes_per_row = A->lanes;
   I.index_patterns = 0;
-  if (A->kernel == MK_SPMV_STREAM) MK_TRY(try_compress_indices(A));
+  if (A->kernel == MK_SPMV_STREAM) {
+    MK_TRY(try_compress<true>(A));                 // offsets and values shared by rows -> pattern kernel
+    if (!A->pat) MK_TRY(try_compress<false>(A));   // offsets only -> stream kernel without col[]
+    if (A->vtab && was_auto) A->kernel = MK_SPMV_PATTERN;
+  }
+  I.kernel = A->kernel;
   I.index_patterns = A->pat ? A->npat : 0;
+  I.value_patterns = A->vtab ? A->npat : 0;
   A->analysed = true;
   return MK_OK;
 }
@@ -596,6 +665,251 @@ static int launch_stream(const mk_matrix *A, double alpha, const double *x, doub
   return fail(MK_ERR_UNSUPPORTED, "spmv: stream capacity %d too large", cap);
 }
 
+// ------------------------------------------------------------------ pattern kernel
+// Rows drawn from a small table of (offsets, values) patterns: constant-coefficient stencils and
+// banded operators.  One lane per row; the only matrix data read from HBM is the 2-byte pattern id,
+// offsets and values come out of LDS (lanes of a wave mostly share a pattern: broadcast reads), so
+// the product is bound by x and y traffic alone.  Each row is summed left to right over the same
+// (column, value) pairs as the CSR arrays hold -> bitwise identical to the serial reference.
+// Lossless by construction: pat_verify_kernel<true> compared every row with its table entry.
+// Chunk = 256 consecutive rows; XCD-contiguous chunk ranges and the optional plane-tiled traversal
+// as in the stream kernel (here the x gathers are most of the traffic, so their L2 reuse matters).
+// WIDE: n * 8 bytes does not fit 32-bit offsets (n >= 2^29 rows): plain 64-bit addressing.  Otherwise every
+// access is base (SGPR pair) + 32-bit byte offset, one v_add_lshl per gather instead of 64-bit pointer math
+// (the first version spent more issue slots on addresses than on loads: 1.14 ms at 512^3).
+template <bool WIDE, typename T>
+__device__ __forceinline__ T ld_at(const T *base, int64_t row, int off) {
+  if (WIDE) return base[row + off];
+  const unsigned byte = ((unsigned)row + (unsigned)off) * (unsigned)sizeof(T);
+  return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + byte);
+}
+template <bool WIDE>
+__device__ __forceinline__ void st_at(double *base, int64_t row, double v) {
+  if (WIDE) { base[row] = v; return; }
+  *reinterpret_cast<double *>(reinterpret_cast<char *>(base) + ((unsigned)row << 3)) = v;
+}
+
+// tables: otab = per pattern [len, 7 x pad, offsets padded with 0 up to P8 (a multiple of 8)], vtab = per
+// pattern P8 values padded with 0.0: a padded slot addresses x[row], which exists, and is never added.
+// A wave whose lanes all carry the same pattern (interior rows) reads offsets and values with scalar
+// loads from the global copy of the tables (no vector instruction per entry except the gather and the
+// fma); mixed waves (boundary rows) read the LDS copy.
+typedef double d2u_t __attribute__((ext_vector_type(2), aligned(8)));   // 16-byte access that is only 8-byte aligned
+
+template <int MODE, bool WIDE>
+__global__ __launch_bounds__(kThreads) void spmv_pattern_kernel(
+    int64_t nrows, const unsigned short *__restrict__ pat, const int *__restrict__ otab, const double *__restrict__ vtab,
+    int npat, int P8, const double *__restrict__ x, double *__restrict__ y, double alpha, double beta,
+    double *__restrict__ slab, const int *__restrict__ done, const double *__restrict__ rhs, const double *__restrict__ extra,
+    int tile_p, int tile_t) {
+  if (done != nullptr && *done != 0) return;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int SP = P8 + 8;
+  double *sv = reinterpret_cast<double *>(smem_raw);                             // npat * P8 values (>= 8 doubles: reduction scratch)
+  int *st = reinterpret_cast<int *>(smem_raw + (size_t)max(npat * P8, 8) * 8);   // npat * SP
+  for (int i = threadIdx.x; i < npat * P8; i += kThreads) sv[i] = vtab[i];
+  for (int i = threadIdx.x; i < npat * SP; i += kThreads) st[i] = otab[i];
+  __syncthreads();
+  const int tid = threadIdx.x;
+  constexpr int CR = kPatternChunkRows;   // rows per chunk: every lane owns two consecutive rows
+  const int64_t nchunks = (nrows + CR - 1) / CR;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
+  const int64_t per_xcd = (nchunks + 7) / 8;
+  const int64_t first = xcd * per_xcd, last = min(first + per_xcd, nchunks);
+  const int64_t span = last > first ? last - first : 0;
+  const int64_t planes = tile_p > 0 ? (span + tile_p - 1) / tile_p : 0;
+  const int64_t per_tile = planes * tile_t;
+  const int64_t total_q = tile_p > 0 ? ((tile_p + tile_t - 1) / tile_t) * per_tile : span;
+  double acc0 = 0.0, acc1 = 0.0;
+
+  // one row, table entry read per lane from LDS (mixed waves: grid boundaries, the ragged last chunk)
+  auto one_row = [&](int64_t row, int pid) {
+    const double xr = (MODE != 0) ? ld_at<WIDE>(x, row, 0) : 0.0;
+    const double yold = (MODE == 0 && beta != 0.0) ? ld_at<WIDE>(y, row, 0) : 0.0;
+    double rhs_r = 0.0;
+    if (MODE == 2) rhs_r = extra ? ld_at<WIDE>(rhs, row, 0) - ld_at<WIDE>(extra, row, 0) : ld_at<WIDE>(rhs, row, 0);
+    const int *t = st + pid * SP;
+    const double *v = sv + pid * P8;
+    const int len = t[0];
+    double sum = 0.0, dv = 0.0;
+    for (int k0 = 0; k0 < len; k0 += 8) {   // 8 gathers in flight per lane before the first is used
+      int oj[8];
+      double xj[8], vj[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) { oj[u] = t[8 + k0 + u]; vj[u] = v[k0 + u]; }
+#pragma unroll
+      for (int u = 0; u < 8; u++) xj[u] = ld_at<WIDE>(x, row, oj[u]);
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        if (k0 + u < len) {
+          sum += vj[u] * xj[u];
+          if (MODE == 2 && oj[u] == 0) dv = vj[u];   // the last stored diagonal entry wins
+        }
+    }
+    if (MODE == 0) {
+      st_at<WIDE>(y, row, (beta == 0.0) ? alpha * sum : alpha * sum + beta * yold);
+    } else if (MODE == 2) {
+      const double res = rhs_r - sum;
+      st_at<WIDE>(y, row, xr + res / dv);
+      acc0 += res * res;
+    } else {
+      st_at<WIDE>(y, row, sum);
+      acc0 += sum * xr;
+      acc1 += xr * xr;
+    }
+  };
+
+  // traversal: position q -> chunk (or a hole of the tiling); tile t of a plane, then all planes of the
+  // range, then the next tile
+  auto next_chunk = [&](int64_t &q) -> int64_t {   // first valid chunk at or after position q (step = slots), else -1
+    for (; q < total_q; q += slots) {
+      if (tile_p <= 0) return first + q;
+      const int64_t t = q / per_tile, rem = q - t * per_tile;
+      const int64_t z = rem / tile_t, i = rem - z * tile_t;
+      const int64_t pos = t * tile_t + i;
+      const int64_t ch = first + z * tile_p + pos;
+      if (pos < tile_p && ch < last) return ch;
+    }
+    return -1;
+  };
+  // the two pattern ids of a lane's rows; issued one chunk ahead so that only the gathers' latency
+  // (not pattern id -> table -> gathers) is exposed per chunk
+  auto load_ids = [&](int64_t chunk) -> unsigned {
+    if (chunk < 0) return 0u;
+    const int64_t row = chunk * CR + 2 * tid;
+    if (row + 1 < nrows) return ld_at<WIDE>(reinterpret_cast<const unsigned *>(pat), row >> 1, 0);
+    if (row < nrows) return (unsigned)ld_at<WIDE>(pat, row, 0);
+    return 0u;
+  };
+  int64_t q = slot;
+  int64_t chunk = next_chunk(q);
+  unsigned pp = load_ids(chunk);
+  while (chunk >= 0) {
+    q += slots;
+    const int64_t chunk_n = next_chunk(q);
+    const unsigned pp_n = load_ids(chunk_n);
+    const int64_t row = chunk * CR + 2 * tid;   // even: 4-byte aligned in pat, 16-byte aligned in x and y
+    const unsigned pp_c = pp;
+    chunk = chunk_n;
+    pp = pp_n;
+    if (row >= nrows) continue;
+    const bool two = row + 1 < nrows;
+    const int pidA = (int)(pp_c & 0xffffu);
+    const int pidB = two ? (int)(pp_c >> 16) : pidA;
+    const int pid0 = __builtin_amdgcn_readfirstlane(pidA);
+    if (__all(two && pidA == pid0 && pidB == pid0)) {
+      // interior wave: 128 rows of one pattern.  Offsets and values by scalar loads from the global
+      // tables; the two rows of a lane gather x[row+off], x[row+1+off] with ONE 16-byte load.
+      const int *__restrict__ t = otab + (size_t)pid0 * SP;
+      const double *__restrict__ v = vtab + (size_t)pid0 * P8;
+      const int len = t[0];
+      d2_t xr = {0.0, 0.0}, yold = {0.0, 0.0}, rh = {0.0, 0.0};   // row is even: these are 16-byte aligned
+      if (MODE != 0) xr = ld_at<WIDE>(reinterpret_cast<const d2_t *>(x), row >> 1, 0);
+      if (MODE == 0 && beta != 0.0) yold = ld_at<WIDE>(reinterpret_cast<const d2_t *>(y), row >> 1, 0);
+      if (MODE == 2) {
+        rh = ld_at<WIDE>(reinterpret_cast<const d2_t *>(rhs), row >> 1, 0);
+        if (extra) rh -= ld_at<WIDE>(reinterpret_cast<const d2_t *>(extra), row >> 1, 0);
+      }
+      double s0 = 0.0, s1 = 0.0, dv = 0.0;
+      for (int k0 = 0; k0 < len; k0 += 8) {
+        int oj[8];
+        double vj[8];
+        d2u_t xj[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { oj[u] = t[8 + k0 + u]; vj[u] = v[k0 + u]; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          if (WIDE) {
+            xj[u] = *reinterpret_cast<const d2u_t *>(x + row + oj[u]);
+          } else {
+            const unsigned byte = ((unsigned)row + (unsigned)oj[u]) << 3;
+            xj[u] = *reinterpret_cast<const d2u_t *>(reinterpret_cast<const char *>(x) + byte);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+          if (k0 + u < len) {
+            s0 += vj[u] * xj[u].x;
+            s1 += vj[u] * xj[u].y;
+            if (MODE == 2 && oj[u] == 0) dv = vj[u];
+          }
+      }
+      d2_t out;
+      if (MODE == 0) {
+        out.x = (beta == 0.0) ? alpha * s0 : alpha * s0 + beta * yold.x;
+        out.y = (beta == 0.0) ? alpha * s1 : alpha * s1 + beta * yold.y;
+      } else if (MODE == 2) {
+        const double r0 = rh.x - s0, r1 = rh.y - s1;
+        out.x = xr.x + r0 / dv;
+        out.y = xr.y + r1 / dv;
+        acc0 += r0 * r0;
+        acc0 += r1 * r1;
+      } else {
+        out.x = s0;
+        out.y = s1;
+        acc0 += s0 * xr.x;
+        acc1 += xr.x * xr.x;
+        acc0 += s1 * xr.y;
+        acc1 += xr.y * xr.y;
+      }
+      if (WIDE) *reinterpret_cast<d2_t *>(y + row) = out;
+      else *reinterpret_cast<d2_t *>(reinterpret_cast<char *>(y) + ((unsigned)row << 3)) = out;
+    } else {
+      one_row(row, pidA);
+      if (two) one_row(row + 1, pidB);
+    }
+  }
+  if (MODE != 0) {
+    __syncthreads();   // the value table doubles as reduction scratch
+    double w[2] = {acc0, acc1};
+    block_sum<2, kThreads>(w, sv);
+    if (threadIdx.x == 0) {
+      slab[0 * kSlabStride + blockIdx.x] = w[0];
+      if (MODE == 1) slab[1 * kSlabStride + blockIdx.x] = w[1];
+    }
+  }
+}
+
+template <int MODE>
+static int launch_pattern(const mk_matrix *A, double alpha, const double *x, double beta, double *y, double *slab,
+                          const int *done, int *nblocks, const double *rhs = nullptr, const double *extra = nullptr) {
+  Context &c = ctx();
+  if (!A->vtab) return fail(MK_ERR_UNSUPPORTED, "spmv: the pattern kernel needs a matrix whose rows share offsets and values");
+  const int P8 = A->p8;
+  const size_t lds = (size_t)std::max(A->npat * P8, 8) * 8 + (size_t)A->npat * (P8 + 8) * 4;
+  const int64_t nchunks = (A->nrows + kPatternChunkRows - 1) / kPatternChunkRows;
+  static const int env_wide = getenv("MK_PATTERN_WIDE") ? atoi(getenv("MK_PATTERN_WIDE")) : 0;   // tests: force 64-bit addressing
+  const bool wide = env_wide || (A->nrows + 8) * 8 >= (int64_t)1 << 32 || A->ncols * 8 >= (int64_t)1 << 32;
+  static const int env_bpc = getenv("MK_PATTERN_BPC") ? atoi(getenv("MK_PATTERN_BPC")) : 0;
+  int per_cu = env_bpc > 0 ? env_bpc : A->pattern_bpc[MODE];
+  if (per_cu <= 0) {
+    int occ = 0;
+    hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, spmv_pattern_kernel<MODE, false>, kThreads, lds);
+    per_cu = (oe == hipSuccess && occ > 0) ? std::min(occ, 8) : 4;
+    A->pattern_bpc[MODE] = per_cu;
+  }
+  int64_t blocks = std::min<int64_t>((nchunks + 7) / 8 * 8, (int64_t)c.num_cus * per_cu);
+  blocks = std::max<int64_t>(8, blocks / 8 * 8);
+  if (blocks > kSlabStride) blocks = kSlabStride;
+  if (nblocks) *nblocks = (int)blocks;
+  // plane-tiled traversal when the operator couples rows more than ~1.5 MB of x apart (3D grids):
+  // tile_p = that stride in chunks, tile_t = chunks of one plane walked before moving to the next plane
+  static const int env_tile = getenv("MK_PATTERN_TILE") ? atoi(getenv("MK_PATTERN_TILE")) : 0;
+  int tile_p = 0, tile_t = 0;
+  if (env_tile > 0 && A->max_off % kPatternChunkRows == 0 && A->max_off / kPatternChunkRows >= 4 * env_tile && 24.0 * A->max_off > 1.5e6) {
+    tile_p = A->max_off / kPatternChunkRows;
+    tile_t = env_tile;
+  }
+  if (wide)
+    hipLaunchKernelGGL((spmv_pattern_kernel<MODE, true>), dim3((unsigned)blocks), dim3(kThreads), lds, c.stream, A->nrows, A->pat,
+                       A->otab8, A->vtab8, A->npat, P8, x, y, alpha, beta, slab, done, rhs, extra, tile_p, tile_t);
+  else
+    hipLaunchKernelGGL((spmv_pattern_kernel<MODE, false>), dim3((unsigned)blocks), dim3(kThreads), lds, c.stream, A->nrows, A->pat,
+                       A->otab8, A->vtab8, A->npat, P8, x, y, alpha, beta, slab, done, rhs, extra, tile_p, tile_t);
+  MK_HIP(hipGetLastError());
+  return MK_OK;
+}
+
 // -------------------------------------------------------------------- split kernel
 // Skewed / power-law rows.  Work is cut by ENTRIES, not rows: chunk c owns entries
 // [c*CH, (c+1)*CH), so every block streams the same number of bytes whatever the row lengths
@@ -767,6 +1081,7 @@ static int launch_split(const mk_matrix *A, double alpha, const double *x, doubl
 int launch_spmv(const mk_matrix *A, double alpha, const double *x, double beta, double *y) {
   MK_TRY(analyse_matrix(const_cast<mk_matrix *>(A)));
   if (A->nrows == 0) return MK_OK;
+  if (A->kernel == MK_SPMV_PATTERN) return launch_pattern<0>(A, alpha, x, beta, y, nullptr, nullptr, nullptr);
   if (A->kernel == MK_SPMV_STREAM) return launch_stream<0>(A, alpha, x, beta, y, nullptr, nullptr, nullptr);
   if (A->kernel == MK_SPMV_SPLIT) return launch_split<0>(A, alpha, x, beta, y, nullptr, nullptr, nullptr);
   return launch_vector<0>(A, alpha, x, beta, y, nullptr, nullptr, nullptr);
@@ -777,12 +1092,14 @@ int launch_spmv(const mk_matrix *A, double alpha, const double *x, double beta, 
 int launch_jacobi_sweep(const mk_matrix *A, const double *rhs, const double *extra, const double *xold, double *xnew,
                         double *slab, const int *done, int *nblocks) {
   MK_TRY(analyse_matrix(const_cast<mk_matrix *>(A)));
+  if (A->kernel == MK_SPMV_PATTERN) return launch_pattern<2>(A, 1.0, xold, 0.0, xnew, slab, done, nblocks, rhs, extra);
   if (A->kernel != MK_SPMV_STREAM) return MK_ERR_UNSUPPORTED;
   return launch_stream<2>(A, 1.0, xold, 0.0, xnew, slab, done, nblocks, rhs, extra);
 }
 
 int launch_spmv_dot(const mk_matrix *A, const double *x, double *y, double *slab, const int *done, int *nblocks) {
   MK_TRY(analyse_matrix(const_cast<mk_matrix *>(A)));
+  if (A->kernel == MK_SPMV_PATTERN) return launch_pattern<1>(A, 1.0, x, 0.0, y, slab, done, nblocks);
   if (A->kernel == MK_SPMV_STREAM) return launch_stream<1>(A, 1.0, x, 0.0, y, slab, done, nblocks);
   if (A->kernel == MK_SPMV_SPLIT) return launch_split<1>(A, 1.0, x, 0.0, y, slab, done, nblocks);
   return launch_vector<1>(A, 1.0, x, 0.0, y, slab, done, nblocks);
@@ -842,8 +1159,11 @@ int mk_matrix_set_spmv_kernel(mk_matrix *A, int kernel, int lanes_per_row) {
   MK_REQUIRE_INIT();
   if (!A) return fail(MK_ERR_INVALID, "mk_matrix_set_spmv_kernel: null matrix");
   MK_TRY(analyse_matrix(A));
-  if (kernel != MK_SPMV_AUTO && kernel != MK_SPMV_VECTOR && kernel != MK_SPMV_STREAM && kernel != MK_SPMV_SPLIT)
+  if (kernel != MK_SPMV_AUTO && kernel != MK_SPMV_VECTOR && kernel != MK_SPMV_STREAM && kernel != MK_SPMV_SPLIT &&
+      kernel != MK_SPMV_PATTERN)
     return fail(MK_ERR_INVALID, "mk_matrix_set_spmv_kernel: unknown kernel %d", kernel);
+  if (kernel == MK_SPMV_PATTERN && !A->vtab)
+    return fail(MK_ERR_UNSUPPORTED, "mk_matrix_set_spmv_kernel: the rows of this matrix do not share (offsets, values) patterns");
   if (lanes_per_row != 0) {
     if (lanes_per_row < 1 || lanes_per_row > 64 || (lanes_per_row & (lanes_per_row - 1)))
       return fail(MK_ERR_INVALID, "mk_matrix_set_spmv_kernel: lanes_per_row must be a power of two in 1..64");

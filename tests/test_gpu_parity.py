@@ -158,6 +158,81 @@ def test_spmv_stream_kernel_stencils(kind, dims):
     _check_spmv(A, rp, ci, v, n, n, rng)
 
 
+@pytest.mark.parametrize("kind,dims", [(5, (33, 17, 1)), (7, (19, 11, 13)), (27, (9, 10, 11)), (7, (64, 64, 40))])
+def test_spmv_pattern_kernel_constant_coefficients(kind, dims):
+    """rows of a constant-coefficient stencil share offsets AND values: the pattern kernel reads 2 B of
+    matrix data per row and must give the serial reference's bits (one lane per row, left to right)"""
+    rng = np.random.default_rng(kind + 100)
+    rp, ci, v = oracle.stencil_csr(kind, *dims)
+    n = rp.size - 1
+    A = mk.Matrix.from_csr(n, n, rp, ci, v)
+    i = A.info()
+    assert i.kernel == mk.SPMV_PATTERN and 1 <= i.value_patterns <= 27 and i.value_patterns == i.index_patterns
+    xh = rng.normal(size=n)
+    x, y = mk.Vector(n, values=xh), mk.Vector(n)
+    A.spmv(x, y)
+    ref = oracle.csr_spmv(rp, ci, v, xh)
+    assert np.array_equal(y.get(), ref)
+    yx, xx = A.spmv_dot(x, y)
+    assert np.array_equal(y.get(), ref)
+    assert abs(yx - ref @ xh) <= 1e-12 * np.abs(ref * xh).sum() and abs(xx - xh @ xh) <= 1e-12 * (xh @ xh)
+    _check_spmv(A, rp, ci, v, n, n, rng, alpha=-1.0, beta=1.0)
+    _check_spmv(A, rp, ci, v, n, n, rng, alpha=0.5, beta=-2.0)
+    # the CSR arrays are still there: other kernels on the same matrix, and the download
+    for k in (mk.SPMV_STREAM, mk.SPMV_VECTOR, mk.SPMV_SPLIT, mk.SPMV_PATTERN):
+        A.set_spmv_kernel(k)
+        _check_spmv(A, rp, ci, v, n, n, rng)
+    rp2, ci2, v2 = A.to_csr()
+    assert np.array_equal(rp2, rp) and np.array_equal(ci2, ci) and np.array_equal(v2.view(np.uint64), v.view(np.uint64))
+
+
+def test_spmv_pattern_kernel_value_edge_cases():
+    """-0.0 and +0.0 are different table entries (bit compare), rows with distinct values fall back to
+    index-only compression, and the pattern kernel is refused for them"""
+    n = 4096
+    rp = np.arange(0, 2 * n + 1, 2, dtype=np.int32)
+    ci = np.stack([np.arange(n), (np.arange(n) + 1) % n]).T.copy()
+    ci[-1] = [n - 1, n - 1]
+    ci = ci.reshape(-1).astype(np.int32)
+    v = np.tile([2.0, 0.0], n)
+    v[1::4] = -0.0                                        # every other row stores -0.0
+    A = mk.Matrix.from_csr(n, n, rp, ci, v)
+    i = A.info()
+    assert i.kernel == mk.SPMV_PATTERN and i.value_patterns == 3      # interior rows with +0.0, with -0.0, and the last row
+    xh = -np.ones(n)
+    x, y = mk.Vector(n, values=xh), mk.Vector(n)
+    A.spmv(x, y)
+    assert np.array_equal(y.get().view(np.uint64), oracle.csr_spmv(rp, ci, v, xh).view(np.uint64))
+    v3 = np.random.default_rng(0).normal(size=2 * n)
+    B = mk.Matrix.from_csr(n, n, rp, ci, v3)
+    assert B.info().kernel == mk.SPMV_STREAM and B.info().value_patterns == 0 and B.info().index_patterns == 2
+    with pytest.raises(mk.MkError):
+        B.set_spmv_kernel(mk.SPMV_PATTERN)
+
+
+def test_spmv_pattern_kernel_wide_addressing():
+    """matrices of 2^29 rows or more use plain 64-bit addressing in the pattern kernel; that build is
+    forced here on a small operator (MK_PATTERN_WIDE is read once per process, hence the child)"""
+    import subprocess, sys
+    code = (
+        "import numpy as np, iterative_solvers_amd as mk\n"
+        "from oracle import stencil_csr, csr_spmv\n"
+        "rp, ci, v = stencil_csr(7, 40, 24, 12)\n"
+        "n = rp.size - 1\n"
+        "A = mk.Matrix.from_csr(n, n, rp, ci, v)\n"
+        "assert A.info().kernel == mk.SPMV_PATTERN\n"
+        "xh = np.random.default_rng(1).normal(size=n)\n"
+        "x, y = mk.Vector(n, values=xh), mk.Vector(n)\n"
+        "A.spmv(x, y)\n"
+        "assert np.array_equal(y.get(), csr_spmv(rp, ci, v, xh))\n"
+        "yx, xx = A.spmv_dot(x, y)\n"
+        "assert np.array_equal(y.get(), csr_spmv(rp, ci, v, xh))\n"
+        "print('wide ok')\n")
+    env = dict(os.environ, MK_PATTERN_WIDE="1", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    o = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=110)
+    assert o.returncode == 0 and "wide ok" in o.stdout, o.stderr[-2000:]
+
+
 def test_spmv_index_compression_is_lossless_and_optional():
     """random short rows have ~n distinct patterns: the table would not fit, so the plain stream
     kernel runs; a block-structured matrix with a few hundred patterns is compressed; both must

@@ -10,7 +10,7 @@ kind, nx, ny, nz = (int(a) for a in sys.argv[1:5]) if len(sys.argv) >= 5 else (7
 reps = int(sys.argv[5]) if len(sys.argv) > 5 else 20
 kernel = int(os.environ.get("MK_PROBE_KERNEL", "0"))
 mk.init(0)
-A = mk.Matrix.stencil(kind, nx, ny, nz)
+A = mk.Matrix.banded(nx, hb=ny) if kind == 0 else mk.Matrix.stencil(kind, nx, ny, nz)   # kind 0: banded, n = nx, half bandwidth = ny
 if kernel:
     A.set_spmv_kernel(kernel, int(os.environ.get("MK_PROBE_LANES", "0")))
 n = A.nrows
@@ -23,5 +23,5 @@ for _ in range(reps):
 ms = mk.timer_stop() / reps
 b = 12 * A.nnz + 20 * n + 4
 i = A.info()
-print(f"kind={kind} {nx}x{ny}x{nz} kernel={i.kernel} patterns={i.index_patterns} spmv+dot {ms*1e3:.1f} us  "
+print(f"kind={kind} {nx}x{ny}x{nz} kernel={i.kernel} patterns={i.index_patterns}/{i.value_patterns} spmv+dot {ms*1e3:.1f} us  "
       f"{b/ms/1e6:.1f} GB/s  ({b/ms/1e6/8000:.3f} of 8 TB/s)")
