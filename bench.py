@@ -129,12 +129,12 @@ def main():
     for _ in range(reps):
         A.spmv_dot(b, s, want=False)
     spmv_ms = mk.timer_stop() / reps
-    kname = {1: "vector", 2: "stream", 3: "split", 4: "pattern"}.get(info.kernel, str(info.kernel))
+    kname = {1: "vector", 2: "stream", 3: "split", 4: "pattern", 5: "sweep"}.get(info.kernel, str(info.kernel))
     csr_bytes = 12 * nnz + 20 * n + 4           # val 8 + col 4 per entry, rowptr 4 + x 8 + y 8 per row
-    # the pattern kernel (rows drawn from a table of (offsets, values) patterns) reads none of the CSR
+    # the pattern and sweep kernels (rows drawn from a table of (offsets, values) patterns) read none of the CSR
     # arrays: its algorithmic bytes are the 2-byte pattern id, x and y per row.  The roofline is priced
     # on what the kernel that ran has to move; the CSR-model rate is reported beside it.
-    spmv_bytes = 18 * n + 4 if info.kernel == 4 else csr_bytes
+    spmv_bytes = 18 * n + 4 if info.kernel in (4, 5) else csr_bytes
     achieved = spmv_bytes / (spmv_ms * 1e-3) / 1e9
     vec_bytes = (88 if precond else 72) * n     # K2 + K3: x, p, r, s (and 1/diag) streams
     iter_bytes = spmv_bytes + vec_bytes
@@ -166,7 +166,7 @@ def main():
         A2, b2, dt2, res2 = measure(sname, args.steps, args.warmup)
         out["secondary"] = {sname: {"workload": WORKLOADS[sname][5], "value": round(args.steps / dt2, 2),
                                     "unit": "CG iterations/s", "ms_per_step": round(dt2 * 1e3 / args.steps, 4),
-                                    "spmv_kernel": {1: "vector", 2: "stream", 3: "split", 4: "pattern"}.get(A2.info().kernel),
+                                    "spmv_kernel": {1: "vector", 2: "stream", 3: "split", 4: "pattern", 5: "sweep"}.get(A2.info().kernel),
                                     "iteration_csr_model_GBps": round((12 * A2.nnz + 108 * A2.nrows) / (dt2 / args.steps) / 1e9, 1)}}
         del A2, b2
     if not args.no_cpu_baseline:

@@ -116,8 +116,11 @@ typedef enum {
   MK_SPMV_STREAM = 2,      /* regular rows: 256/G consecutive rows per chunk staged through LDS, one pass per row group */
   MK_SPMV_SPLIT = 3,       /* skewed rows: nnz-balanced chunks (merge-path style), products staged in LDS, rows split
                               inside and across chunks, carries folded in a fixed order by a second small kernel */
-  MK_SPMV_PATTERN = 4      /* rows drawn from a small table of (offsets, values) patterns: one lane per row, 2 B of
+  MK_SPMV_PATTERN = 4,     /* rows drawn from a small table of (offsets, values) patterns: one lane per row, 2 B of
                               matrix data per row; only when mk_matrix_info.value_patterns > 0 */
+  MK_SPMV_SWEEP = 5        /* pattern matrices whose rows are all sub-lists of ONE pattern with offsets a*P + b (grids):
+                              a block sweeps plane by plane with the x window of three planes in LDS, so every x entry
+                              is loaded once per block instead of once per neighbour */
 } mk_spmv_kernel;
 /* override the selector (lanes_per_row: 0 = keep, else 1..64 power of two) */
 int mk_matrix_set_spmv_kernel(mk_matrix *A, int kernel, int lanes_per_row);

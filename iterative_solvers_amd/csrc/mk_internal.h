@@ -64,6 +64,23 @@ inline void dev_free(void *p) {
   if (p) (void)hipFree(p);
 }
 
+// kernel argument (by value) of spmv_sweep_kernel: the one base pattern every row is a sub-list of,
+// each offset split as a * P + b (P = sweep stride, e.g. one grid plane; |b| small), and the geometry
+struct SweepArgs {
+  int len;        // entries of the base pattern
+  int P;          // rows between consecutive sweep steps of a block (even); == C in contiguous mode
+  int ncp;        // chunks of C rows per plane
+  int nseg;       // segments the K planes are cut into (grid = ncp * nseg blocks, set per launch)
+  int wlo, sw;    // window: rows [r0 - wlo, r0 - wlo + sw) of a plane per slab (both even)
+  int K;          // planes = ceil(nrows / P)
+  int diag;       // index of the last entry with offset 0, or -1
+  double dv;      // its value
+};
+struct SweepEntry {   // one entry of the base pattern; 32 of them (padded with zeros) in device memory
+  int a, b;
+  double v;
+};
+
 // ---------------------------------------------------------------------------- objects
 }  // namespace mk
 
@@ -107,6 +124,11 @@ struct mk_matrix {
   int *otab8 = nullptr;            // pattern kernel's padded copies of ptab / vtab (row stride p8 + 8 ints, p8 doubles)
   double *vtab8 = nullptr;
   int p8 = 0;
+  mk::SweepArgs *sweep = nullptr;  // host copy of the sweep kernel's plan (nullptr: not eligible)
+  unsigned *pmask = nullptr;       // device, npat: which entries of the base pattern each pattern keeps
+  mk::SweepEntry *etab = nullptr;  // device, 32 entries
+  bool sweep_auto = false;         // enough parallelism for the sweep kernel to be the default
+  mutable int sweep_bpc[3] = {0, 0, 0};
   int npat = 0, pml = 0;
   int max_off = 0;                 // largest |column - row| over all patterns
   // split kernel: chunk c covers entries [c*kSplitChunk, (c+1)*kSplitChunk); chunk_row[c] = first row starting in it

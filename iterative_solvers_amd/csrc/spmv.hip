@@ -176,6 +176,88 @@ __global__ void pat_verify_kernel(int64_t nrows, const int *__restrict__ rowptr,
 constexpr int kPatMaxValBytes = 32768;
 constexpr int kPatternChunkRows = 2 * kThreads;   // pattern kernel: rows per chunk   // value table (doubles) beside the offset table in LDS
 
+constexpr int kSweepC = 2 * kThreads;   // rows per chunk of the sweep kernel (two per lane)
+constexpr int kSweepNS = 4;             // ring slots: planes k-1, k, k+1 and the one being written
+constexpr int kSweepNL = 4;             // 16-byte loads per thread per slab -> window <= 2048 entries
+constexpr int kSweepMaxLds = 64 * 1024 - 512;
+
+// Can the sweep kernel serve this matrix?  tab/vals: the (offsets, values) pattern table.
+static int plan_sweep(mk_matrix *A, const std::vector<int> &tab, const std::vector<double> &vals) {
+  static const int off = getenv("MK_NO_SWEEP") ? atoi(getenv("MK_NO_SWEEP")) : 0;
+  const int npat = A->npat, pml = A->pml;
+  if (off || pml > 32 || (A->nrows + 8) * 8 >= (int64_t)1 << 32 || A->ncols * 8 >= (int64_t)1 << 32) return MK_OK;
+  auto len_of = [&](int q) { return tab[(size_t)q * (pml + 1)]; };
+  auto off_of = [&](int q, int k) { return tab[(size_t)q * (pml + 1) + 1 + k]; };
+  auto bits_of = [&](int q, int k) { unsigned long long u; memcpy(&u, &vals[(size_t)q * pml + k], 8); return u; };
+  int base = 0;
+  for (int q = 1; q < npat; q++) if (len_of(q) > len_of(base)) base = q;
+  const int len = len_of(base);
+  if (len < 1) return MK_OK;
+  // every pattern must be a sub-list (same order, same offsets, same value bits) of the base
+  std::vector<unsigned> mask(npat, 0u);
+  for (int q = 0; q < npat; q++) {
+    int u = 0;
+    for (int k = 0; k < len_of(q); k++) {
+      while (u < len && !(off_of(base, u) == off_of(q, k) && bits_of(base, u) == bits_of(q, k))) u++;
+      if (u == len) return MK_OK;
+      mask[q] |= 1u << u;
+      u++;
+    }
+  }
+  SweepArgs S;
+  memset(&S, 0, sizeof(S));
+  SweepEntry E[32];
+  memset(E, 0, sizeof(E));
+  S.len = len;
+  int maxabs = 0;
+  for (int u = 0; u < len; u++) maxabs = std::max(maxabs, std::abs(off_of(base, u)));
+  if (maxabs <= 768) {   // banded: contiguous sweep, every offset is "near"
+    S.P = kSweepC;
+    for (int u = 0; u < len; u++) { E[u].a = 0; E[u].b = off_of(base, u); }
+  } else {
+    // far offsets cluster around +-P: P = centre of the cluster that holds the largest |offset|
+    int lo = maxabs, hi = maxabs;
+    for (int u = 0; u < len; u++) {
+      const int o = std::abs(off_of(base, u));
+      if (2 * o > maxabs) lo = std::min(lo, o);
+    }
+    const int P = (lo + hi) / 2;
+    if (P < 2 || (P & 1) || ((lo + hi) & 1)) return MK_OK;
+    S.P = P;
+    for (int u = 0; u < len; u++) {
+      const int o = off_of(base, u);
+      const int a = (o > P / 2) ? 1 : (o < -(P / 2)) ? -1 : 0;
+      E[u].a = a;
+      E[u].b = o - a * P;
+    }
+  }
+  int bmin = 0, bmax = 0;
+  S.diag = -1;
+  for (int u = 0; u < len; u++) {
+    bmin = std::min(bmin, E[u].b);
+    bmax = std::max(bmax, E[u].b);
+    E[u].v = vals[(size_t)base * pml + u];
+    if (off_of(base, u) == 0) { S.diag = u; S.dv = E[u].v; }
+  }
+  S.wlo = (-bmin + 1) & ~1;
+  const int whi = (bmax + 1) & ~1;
+  S.sw = kSweepC + S.wlo + whi;
+  if (S.sw > 2 * kThreads * kSweepNL) return MK_OK;
+  if ((size_t)kSweepNS * S.sw * 8 + (size_t)npat * 4 > (size_t)kSweepMaxLds) return MK_OK;
+  S.K = (int)((A->nrows + S.P - 1) / S.P);
+  S.ncp = (S.P + kSweepC - 1) / kSweepC;
+  S.nseg = 1;
+  MK_TRY(dev_alloc(&A->pmask, (size_t)npat));
+  MK_TRY(dev_alloc(&A->etab, 4 * 32));
+  MK_HIP(hipMemcpyAsync(A->pmask, mask.data(), sizeof(unsigned) * npat, hipMemcpyHostToDevice, ctx().stream));
+  for (int cpy = 0; cpy < 4; cpy++) MK_HIP(hipMemcpyAsync(A->etab + cpy * 32, E, sizeof(E), hipMemcpyHostToDevice, ctx().stream));
+  MK_HIP(hipStreamSynchronize(ctx().stream));
+  A->sweep = new SweepArgs(S);
+  // default only when the grid can fill the chip: ncp chunks per plane times segments of >= 8 planes
+  A->sweep_auto = (int64_t)S.ncp * std::max(1, S.K / 8) >= 2 * (int64_t)ctx().num_cus;
+  return MK_OK;
+}
+
 // with_values: key = (offsets, values); the pattern kernel then needs neither col[] nor val[] nor rowptr[]
 template <bool VAL>
 static int try_compress(mk_matrix *A) {
@@ -246,6 +328,7 @@ static int try_compress(mk_matrix *A) {
         MK_HIP(hipMemcpyAsync(A->vtab8, v8.data(), sizeof(double) * v8.size(), hipMemcpyHostToDevice, c.stream));
         MK_HIP(hipStreamSynchronize(c.stream));
         A->p8 = P8;
+        MK_TRY(plan_sweep(A, tab, vals));
       }
     }
   }
@@ -299,7 +382,7 @@ int analyse_matrix(mk_matrix *A) {
   if (A->kernel == MK_SPMV_STREAM) {
     MK_TRY(try_compress<true>(A));                 // offsets and values shared by rows -> pattern kernel
     if (!A->pat) MK_TRY(try_compress<false>(A));   // offsets only -> stream kernel without col[]
-    if (A->vtab && was_auto) A->kernel = MK_SPMV_PATTERN;
+    if (A->vtab && was_auto) A->kernel = (A->sweep && A->sweep_auto) ? MK_SPMV_SWEEP : MK_SPMV_PATTERN;
   }
   I.kernel = A->kernel;
   I.index_patterns = A->pat ? A->npat : 0;
@@ -910,6 +993,235 @@ static int launch_pattern(const mk_matrix *A, double alpha, const double *x, dou
   return MK_OK;
 }
 
+// -------------------------------------------------------------------- sweep kernel
+// Pattern matrices on grids: every row is a sub-list of ONE base pattern whose offsets split as
+// a * P + b (a in {-1,0,1}: previous / same / next plane, |b| small).  Block (cp, seg) owns rows
+// [cp*C, cp*C + C) of every plane of its segment and walks plane by plane; the x entries of planes
+// k-1, k, k+1 around its rows sit in an LDS ring of four slabs, filled by coalesced 16-byte loads
+// that run three planes ahead in registers.  Every gather becomes an LDS read: the pattern kernel
+// kept ~7 x 8 B per row in flight in registers and was bound by latency x register file, here one
+// 8-byte stream per row feeds LDS and HBM sees x once.  Rows and entries are summed in the order
+// of the CSR arrays (a sub-list keeps the base's order) -> bitwise identical to the serial reference.
+template <int MODE, int NL>   // NL = 16-byte loads per thread per slab = ceil(sw / 512)
+__global__ __launch_bounds__(kThreads) void spmv_sweep_kernel(
+    const SweepArgs S, const SweepEntry *__restrict__ etab, int64_t nrows, int64_t ncols, const unsigned short *__restrict__ pat,
+    const unsigned *__restrict__ pmask, int npat, const double *__restrict__ x, double *__restrict__ y, double alpha, double beta, double *__restrict__ slab,
+    const int *__restrict__ done, const double *__restrict__ rhs, const double *__restrict__ extra) {
+  if (done != nullptr && *done != 0) return;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  constexpr int C = kSweepC, NS = kSweepNS;
+  const int sw = S.sw;
+  double *ring = reinterpret_cast<double *>(smem_raw);            // NS slabs of sw entries
+  unsigned *smask = reinterpret_cast<unsigned *>(ring + NS * sw);   // npat
+  const int tid = threadIdx.x;
+  for (int i = tid; i < npat; i += kThreads) smask[i] = pmask[i];
+  const int nb = gridDim.x;   // multiple of 8; blocks of one XCD take neighbouring chunks of a plane (shared halos in its L2)
+  const int lid = (blockIdx.x & 7) * (nb >> 3) + (blockIdx.x >> 3);
+  double acc0 = 0.0, acc1 = 0.0;
+  if (lid < S.ncp * S.nseg) {
+    const int cp = lid % S.ncp, seg = lid / S.ncp;
+    const int k0 = (int)((int64_t)seg * S.K / S.nseg), k1 = (int)((int64_t)(seg + 1) * S.K / S.nseg);
+    const int r0 = cp * C;
+    const int rows_here = min(C, S.P - r0);
+    const int lr = 2 * tid;
+    const unsigned fullmask = S.len >= 32 ? 0xffffffffu : ((1u << S.len) - 1u);
+    const double dvb = S.diag >= 0 ? S.dv : 0.0;
+
+    // All loads that run ahead are UNCONDITIONAL (addresses clamped into the arrays instead of predicated):
+    // the compiler counts outstanding loads to wait for exactly the one a step needs; a load that may or
+    // may not have been issued would force it to wait for everything.  Clamped positions hold entries no
+    // row refers to (their mask bit is clear) or are never read.
+    const int64_t xlast = (ncols - 1) & ~(int64_t)1;   // x[xlast], x[xlast+1]: inside the allocation (slack behind ncols)
+    const int64_t rlast = (nrows - 1) & ~(int64_t)1;
+    auto load_slab = [&](int j, d2_t(&reg)[NL]) {   // window of plane j
+      const int64_t g0 = (int64_t)min(j, k1) * S.P + r0 - S.wlo;
+#pragma unroll
+      for (int i = 0; i < NL; i++) {
+        const int i2 = tid + i * kThreads;
+        const int64_t g = min(max(g0 + 2 * i2, (int64_t)0), xlast);
+        reg[i] = *reinterpret_cast<const d2_t *>(reinterpret_cast<const char *>(x) + ((unsigned)g << 3));
+      }
+    };
+    auto write_slab = [&](int slot, const d2_t(&reg)[NL]) {
+#pragma unroll
+      for (int i = 0; i < NL; i++) {
+        const int i2 = tid + i * kThreads;
+        if (2 * i2 < sw) *reinterpret_cast<d2_t *>(ring + slot * sw + 2 * i2) = reg[i];
+      }
+    };
+    auto row_of = [&](int j) -> int64_t { return (int64_t)j * S.P + r0 + lr; };
+    auto live = [&](int j) -> bool { return j < k1 && lr < rows_here && row_of(j) < nrows; };
+    auto load_ids = [&](int j) -> unsigned {   // pattern ids of rows g, g+1 (g even); the id behind the last row is slack
+      const int64_t g = min(row_of(j), rlast);
+      return *reinterpret_cast<const unsigned *>(reinterpret_cast<const char *>(pat) + ((unsigned)g << 1));
+    };
+    auto load_pair = [&](const double *p, int j) -> d2_t {   // p[g], p[g+1]; p[nrows] is allocation slack
+      const int64_t g = min(row_of(j), rlast);
+      return *reinterpret_cast<const d2_t *>(reinterpret_cast<const char *>(p) + ((unsigned)g << 3));
+    };
+    const double *aux = (MODE == 2) ? rhs : (MODE == 0 && beta != 0.0) ? y : nullptr;
+
+    // Three register stages, each used in place: stage (k mod 3) holds slab k+2 at step k, is written to the
+    // ring and at once re-loaded with slab k+5 -- no register-to-register rotation (a move of a register
+    // that a load is still filling would wait for that load and serialise the pipeline).
+    d2_t st0[NL], st1[NL], st2[NL];
+    load_slab(k0 - 1, st0);
+    load_slab(k0, st1);
+    load_slab(k0 + 1, st2);
+    write_slab(0, st0);
+    write_slab(1, st1);
+    write_slab(2, st2);
+    // issue order as in the steady state (ids/aux of a plane, then the slab two planes further): the compiler
+    // derives "how many younger loads may stay in flight" from the worst path into the loop, the prologue included
+    d2_t ax0 = {0.0, 0.0}, ax1 = ax0, ax2 = ax0, ex0 = ax0, ex1 = ax0, ex2 = ax0;
+    unsigned id0 = load_ids(k0);
+    if (aux) ax0 = load_pair(aux, k0);
+    if (MODE == 2 && extra) ex0 = load_pair(extra, k0);
+    load_slab(k0 + 2, st0);
+    unsigned id1 = load_ids(k0 + 1);
+    if (aux) ax1 = load_pair(aux, k0 + 1);
+    if (MODE == 2 && extra) ex1 = load_pair(extra, k0 + 1);
+    load_slab(k0 + 3, st1);
+    unsigned id2 = load_ids(k0 + 2);
+    if (aux) ax2 = load_pair(aux, k0 + 2);
+    if (MODE == 2 && extra) ex2 = load_pair(extra, k0 + 2);
+    load_slab(k0 + 4, st2);
+    __syncthreads();
+
+    auto step = [&](int k, d2_t(&st)[NL], unsigned &idr, d2_t &axr, d2_t &exr) {
+      const unsigned id0 = idr;
+      const d2_t ax0 = axr, ex0 = exr;
+      if (live(k)) {
+        const int64_t g = row_of(k);
+        const bool two = g + 1 < nrows;
+        const unsigned mA = smask[id0 & 0xffffu];
+        const unsigned mB = two ? smask[min(id0 >> 16, (unsigned)npat - 1u)] : 0u;
+        const int jb = k - k0 + 1;   // ring position of plane k
+        double s0 = 0.0, s1 = 0.0;
+        const bool all_full = __all((mA & mB) == fullmask);
+        for (int u0 = 0; u0 < S.len; u0 += 8) {
+          // the entries come by scalar loads (two s_load_dwordx16 per batch, scalar cache).  The table is stored
+          // four times and step k reads copy k & 3, so that the compiler re-loads it per step instead of
+          // keeping all 32 entries in SGPRs for the whole kernel (it did, and spilled them: 487 v_readlane per step)
+          const SweepEntry *e = etab + (k & 3) * 32 + u0;
+          double p0[8], p1[8], vv[8];
+#pragma unroll
+          for (int u = 0; u < 8; u++) {
+            const double *w = ring + ((jb + e[u].a) & (NS - 1)) * sw + (S.wlo + e[u].b) + lr;
+            p0[u] = w[0];
+            p1[u] = w[1];
+            vv[u] = e[u].v;
+          }
+          if (all_full) {
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+              if (u0 + u < S.len) { s0 += vv[u] * p0[u]; s1 += vv[u] * p1[u]; }
+          } else {
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+              if (u0 + u < S.len) {
+                if ((mA >> (u0 + u)) & 1u) s0 += vv[u] * p0[u];
+                if ((mB >> (u0 + u)) & 1u) s1 += vv[u] * p1[u];
+              }
+          }
+        }
+        d2_t out;
+        if (MODE == 0) {
+          out.x = (beta == 0.0) ? alpha * s0 : alpha * s0 + beta * ax0.x;
+          out.y = (beta == 0.0) ? alpha * s1 : alpha * s1 + beta * ax0.y;
+        } else {
+          const double *wc = ring + (jb & (NS - 1)) * sw + S.wlo + lr;   // x[g], x[g+1]
+          const double xa = wc[0], xb = wc[1];
+          if (MODE == 2) {
+            const double ra = (ax0.x - ex0.x) - s0, rb = (ax0.y - ex0.y) - s1;
+            const double da = (S.diag >= 0 && ((mA >> S.diag) & 1u)) ? dvb : 0.0;
+            const double db = (S.diag >= 0 && ((mB >> S.diag) & 1u)) ? dvb : 0.0;
+            out.x = xa + ra / da;
+            out.y = xb + rb / db;
+            acc0 += ra * ra;
+            if (two) acc0 += rb * rb;
+          } else {
+            out.x = s0;
+            out.y = s1;
+            acc0 += s0 * xa;
+            acc1 += xa * xa;
+            if (two) { acc0 += s1 * xb; acc1 += xb * xb; }
+          }
+        }
+        if (two) *reinterpret_cast<d2_t *>(reinterpret_cast<char *>(y) + ((unsigned)g << 3)) = out;
+        else *reinterpret_cast<double *>(reinterpret_cast<char *>(y) + ((unsigned)g << 3)) = out.x;
+      }
+      // slab k+2 (loaded three steps ago) into the slot plane k-2 occupied; nobody reads that slot in this step
+      write_slab((k - k0 + 3) & (NS - 1), st);
+      // look-ahead loads into the registers just consumed: ids / aux of plane k+3, slab k+5
+      idr = load_ids(k + 3);
+      if (aux) axr = load_pair(aux, k + 3);
+      if (MODE == 2 && extra) exr = load_pair(extra, k + 3);
+      load_slab(k + 5, st);
+      __syncthreads();
+    };
+    for (int k = k0; k < k1; k += 3) {   // straight-line body: steps at or behind k1 compute nothing (live() is false)
+      step(k, st0, id0, ax0, ex0);
+      step(k + 1, st1, id1, ax1, ex1);
+      step(k + 2, st2, id2, ax2, ex2);
+    }
+  }
+  if (MODE != 0) {
+    __syncthreads();
+    double w[2] = {acc0, acc1};
+    block_sum<2, kThreads>(w, ring);
+    if (threadIdx.x == 0) {
+      slab[0 * kSlabStride + blockIdx.x] = w[0];
+      if (MODE == 1) slab[1 * kSlabStride + blockIdx.x] = w[1];
+    }
+  }
+}
+
+template <int MODE>
+static int launch_sweep(const mk_matrix *A, double alpha, const double *x, double beta, double *y, double *slab,
+                        const int *done, int *nblocks, const double *rhs = nullptr, const double *extra = nullptr) {
+  Context &c = ctx();
+  if (!A->sweep) return fail(MK_ERR_UNSUPPORTED, "spmv: the sweep kernel needs rows that are sub-lists of one pattern with offsets a*P + b");
+  SweepArgs S = *A->sweep;
+  const size_t lds = (size_t)kSweepNS * S.sw * 8 + (size_t)A->npat * 4;
+  static const int env_bpc = getenv("MK_SWEEP_BPC") ? atoi(getenv("MK_SWEEP_BPC")) : 0;
+  int per_cu = env_bpc > 0 ? env_bpc : A->sweep_bpc[MODE];
+  if (per_cu <= 0) {
+    int occ = 0;
+    hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, spmv_sweep_kernel<MODE, 3>, kThreads, lds);
+    per_cu = (oe == hipSuccess && occ > 0) ? std::min(occ, 8) : 2;
+    A->sweep_bpc[MODE] = per_cu;
+  }
+  // segments: fill the chip, but keep at least 8 planes per segment (each segment re-reads two halo planes)
+  static const int env_nseg = getenv("MK_SWEEP_NSEG") ? atoi(getenv("MK_SWEEP_NSEG")) : 0;
+  const int64_t target = (int64_t)c.num_cus * per_cu;
+  // two rounds of resident blocks (measured at 512^3: 1 segment 647 us, 3 segments 542 us, 6 segments 540 us)
+  int nseg = env_nseg > 0 ? env_nseg : (int)std::max<int64_t>(1, (2 * target + S.ncp - 1) / S.ncp);
+  nseg = std::min(nseg, std::max(1, S.K / 8));
+  nseg = std::max(1, std::min(nseg, S.K));
+  while ((int64_t)S.ncp * nseg > kSlabStride - 8 && nseg > 1) nseg--;
+  if ((int64_t)S.ncp * nseg > kSlabStride - 8) return fail(MK_ERR_UNSUPPORTED, "spmv: sweep grid of %d chunks per plane is too large", S.ncp);
+  S.nseg = nseg;
+  const int blocks = (S.ncp * nseg + 7) / 8 * 8;
+  if (nblocks) *nblocks = blocks;
+  const int nl = std::max(2, (S.sw + 2 * kThreads - 1) / (2 * kThreads));
+#define MK_LAUNCH_SW(NLL)                                                                                                  \
+  case NLL:                                                                                                                \
+    hipLaunchKernelGGL((spmv_sweep_kernel<MODE, NLL>), dim3((unsigned)blocks), dim3(kThreads), lds, c.stream, S, A->etab, A->nrows, \
+                       A->ncols, A->pat, A->pmask, A->npat, x, y, alpha, beta, slab, done, rhs, extra);                    \
+    break;
+  switch (nl) {
+    MK_LAUNCH_SW(2)
+    MK_LAUNCH_SW(3)
+    MK_LAUNCH_SW(4)
+    default:
+      return fail(MK_ERR_UNSUPPORTED, "spmv: sweep window of %d entries", S.sw);
+  }
+#undef MK_LAUNCH_SW
+  MK_HIP(hipGetLastError());
+  return MK_OK;
+}
+
 // -------------------------------------------------------------------- split kernel
 // Skewed / power-law rows.  Work is cut by ENTRIES, not rows: chunk c owns entries
 // [c*CH, (c+1)*CH), so every block streams the same number of bytes whatever the row lengths
@@ -1081,6 +1393,7 @@ static int launch_split(const mk_matrix *A, double alpha, const double *x, doubl
 int launch_spmv(const mk_matrix *A, double alpha, const double *x, double beta, double *y) {
   MK_TRY(analyse_matrix(const_cast<mk_matrix *>(A)));
   if (A->nrows == 0) return MK_OK;
+  if (A->kernel == MK_SPMV_SWEEP) return launch_sweep<0>(A, alpha, x, beta, y, nullptr, nullptr, nullptr);
   if (A->kernel == MK_SPMV_PATTERN) return launch_pattern<0>(A, alpha, x, beta, y, nullptr, nullptr, nullptr);
   if (A->kernel == MK_SPMV_STREAM) return launch_stream<0>(A, alpha, x, beta, y, nullptr, nullptr, nullptr);
   if (A->kernel == MK_SPMV_SPLIT) return launch_split<0>(A, alpha, x, beta, y, nullptr, nullptr, nullptr);
@@ -1092,6 +1405,7 @@ int launch_spmv(const mk_matrix *A, double alpha, const double *x, double beta, 
 int launch_jacobi_sweep(const mk_matrix *A, const double *rhs, const double *extra, const double *xold, double *xnew,
                         double *slab, const int *done, int *nblocks) {
   MK_TRY(analyse_matrix(const_cast<mk_matrix *>(A)));
+  if (A->kernel == MK_SPMV_SWEEP) return launch_sweep<2>(A, 1.0, xold, 0.0, xnew, slab, done, nblocks, rhs, extra);
   if (A->kernel == MK_SPMV_PATTERN) return launch_pattern<2>(A, 1.0, xold, 0.0, xnew, slab, done, nblocks, rhs, extra);
   if (A->kernel != MK_SPMV_STREAM) return MK_ERR_UNSUPPORTED;
   return launch_stream<2>(A, 1.0, xold, 0.0, xnew, slab, done, nblocks, rhs, extra);
@@ -1099,6 +1413,7 @@ int launch_jacobi_sweep(const mk_matrix *A, const double *rhs, const double *ext
 
 int launch_spmv_dot(const mk_matrix *A, const double *x, double *y, double *slab, const int *done, int *nblocks) {
   MK_TRY(analyse_matrix(const_cast<mk_matrix *>(A)));
+  if (A->kernel == MK_SPMV_SWEEP) return launch_sweep<1>(A, 1.0, x, 0.0, y, slab, done, nblocks);
   if (A->kernel == MK_SPMV_PATTERN) return launch_pattern<1>(A, 1.0, x, 0.0, y, slab, done, nblocks);
   if (A->kernel == MK_SPMV_STREAM) return launch_stream<1>(A, 1.0, x, 0.0, y, slab, done, nblocks);
   if (A->kernel == MK_SPMV_SPLIT) return launch_split<1>(A, 1.0, x, 0.0, y, slab, done, nblocks);
@@ -1160,8 +1475,10 @@ int mk_matrix_set_spmv_kernel(mk_matrix *A, int kernel, int lanes_per_row) {
   if (!A) return fail(MK_ERR_INVALID, "mk_matrix_set_spmv_kernel: null matrix");
   MK_TRY(analyse_matrix(A));
   if (kernel != MK_SPMV_AUTO && kernel != MK_SPMV_VECTOR && kernel != MK_SPMV_STREAM && kernel != MK_SPMV_SPLIT &&
-      kernel != MK_SPMV_PATTERN)
+      kernel != MK_SPMV_PATTERN && kernel != MK_SPMV_SWEEP)
     return fail(MK_ERR_INVALID, "mk_matrix_set_spmv_kernel: unknown kernel %d", kernel);
+  if (kernel == MK_SPMV_SWEEP && !A->sweep)
+    return fail(MK_ERR_UNSUPPORTED, "mk_matrix_set_spmv_kernel: the rows of this matrix are not sub-lists of one grid pattern");
   if (kernel == MK_SPMV_PATTERN && !A->vtab)
     return fail(MK_ERR_UNSUPPORTED, "mk_matrix_set_spmv_kernel: the rows of this matrix do not share (offsets, values) patterns");
   if (lanes_per_row != 0) {

@@ -210,6 +210,61 @@ def test_spmv_pattern_kernel_value_edge_cases():
         B.set_spmv_kernel(mk.SPMV_PATTERN)
 
 
+@pytest.mark.parametrize("kind,dims", [(7, (64, 64, 40)), (7, (30, 22, 10)), (27, (16, 18, 9)), (27, (40, 40, 6)),
+                                       (5, (128, 96, 1)), (7, (512, 4, 5)), (7, (24, 16, 33))])
+def test_spmv_sweep_kernel(kind, dims):
+    """grid operators whose rows are sub-lists of one pattern: plane-by-plane sweep with the x window in
+    LDS.  Same (column, value) pairs in the same order as the CSR arrays -> the serial reference's bits."""
+    rng = np.random.default_rng(kind + 200)
+    rp, ci, v = oracle.stencil_csr(kind, *dims)
+    n = rp.size - 1
+    A = mk.Matrix.from_csr(n, n, rp, ci, v)
+    A.set_spmv_kernel(mk.SPMV_SWEEP)
+    assert A.info().kernel == mk.SPMV_SWEEP
+    xh = rng.normal(size=n)
+    x, y = mk.Vector(n, values=xh), mk.Vector(n)
+    A.spmv(x, y)
+    ref = oracle.csr_spmv(rp, ci, v, xh)
+    assert np.array_equal(y.get(), ref)
+    yx, xx = A.spmv_dot(x, y)
+    assert np.array_equal(y.get(), ref)
+    assert abs(yx - ref @ xh) <= 1e-12 * np.abs(ref * xh).sum() and abs(xx - xh @ xh) <= 1e-12 * (xh @ xh)
+    _check_spmv(A, rp, ci, v, n, n, rng, alpha=-1.0, beta=1.0)
+    _check_spmv(A, rp, ci, v, n, n, rng, alpha=0.5, beta=-2.0)
+    # whole solves through the sweep kernel agree with the pattern kernel's
+    res = {}
+    for k in (mk.SPMV_SWEEP, mk.SPMV_PATTERN):
+        A.set_spmv_kernel(k)
+        b, x0 = mk.Vector(n, fill=1.0), mk.Vector(n, fill=0.0)
+        S = mk.PCG(max_iter=300, tol=1e-9, precond=mk.PRECOND_JACOBI)
+        S.setup(A, b, x0)
+        r = S.solve(A, b, x0)
+        J = mk.Jacobi(max_iter=40, tol=1e-30, check_every=7)
+        xj = mk.Vector(n, fill=0.0)
+        J.setup(A, b, xj)
+        rj = J.solve(A, b, xj)
+        res[k] = (r, x0.get(), rj, xj.get())
+    assert res[mk.SPMV_SWEEP][0]["iterations"] == res[mk.SPMV_PATTERN][0]["iterations"]
+    assert np.allclose(res[mk.SPMV_SWEEP][1], res[mk.SPMV_PATTERN][1], rtol=1e-10, atol=1e-12)
+    assert np.array_equal(res[mk.SPMV_SWEEP][3], res[mk.SPMV_PATTERN][3])      # Jacobi sweeps: same bits per row
+
+
+def test_spmv_sweep_kernel_eligibility():
+    rp, ci, v = oracle.stencil_csr(7, 31, 29, 3)           # plane of 899 rows: odd stride, a lane's two rows would straddle planes
+    n = rp.size - 1
+    A = mk.Matrix.from_csr(n, n, rp, ci, v)
+    assert A.info().kernel == mk.SPMV_PATTERN
+    with pytest.raises(mk.MkError):
+        A.set_spmv_kernel(mk.SPMV_SWEEP)
+    B = mk.Matrix.banded(1 << 22, hb=3)                      # contiguous mode, enough chunks to be the default
+    assert B.info().kernel == mk.SPMV_SWEEP
+    rpb, cib, vb = B.to_csr()
+    xh = np.random.default_rng(5).normal(size=1 << 22)
+    x, y = mk.Vector(1 << 22, values=xh), mk.Vector(1 << 22)
+    B.spmv(x, y)
+    assert np.array_equal(y.get(), oracle.csr_spmv(rpb, cib, vb, xh))
+
+
 def test_spmv_pattern_kernel_wide_addressing():
     """matrices of 2^29 rows or more use plain 64-bit addressing in the pattern kernel; that build is
     forced here on a small operator (MK_PATTERN_WIDE is read once per process, hence the child)"""
