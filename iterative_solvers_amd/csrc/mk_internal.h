@@ -76,8 +76,9 @@ struct SweepArgs {
   int diag;       // index of the last entry with offset 0, or -1
   double dv;      // its value
 };
-struct SweepEntry {   // one entry of the base pattern; 32 of them (padded with zeros) in device memory
-  int a, b;
+struct SweepEntry {   // one entry of the base pattern.  Device table: 4 copies x 32 entries (padded with zeros);
+  int off;            // copy c serves the steps whose plane sits in ring slot c: off = byte offset in the LDS ring
+  int pad;            // of the x entry this matrix entry multiplies, for the lane that owns row r0 of the chunk
   double v;
 };
 

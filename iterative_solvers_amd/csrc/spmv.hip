@@ -206,14 +206,14 @@ static int plan_sweep(mk_matrix *A, const std::vector<int> &tab, const std::vect
   }
   SweepArgs S;
   memset(&S, 0, sizeof(S));
-  SweepEntry E[32];
-  memset(E, 0, sizeof(E));
+  int ea[32] = {0}, eb[32] = {0};
+  double ev[32] = {0.0};
   S.len = len;
   int maxabs = 0;
   for (int u = 0; u < len; u++) maxabs = std::max(maxabs, std::abs(off_of(base, u)));
   if (maxabs <= 768) {   // banded: contiguous sweep, every offset is "near"
     S.P = kSweepC;
-    for (int u = 0; u < len; u++) { E[u].a = 0; E[u].b = off_of(base, u); }
+    for (int u = 0; u < len; u++) { ea[u] = 0; eb[u] = off_of(base, u); }
   } else {
     // far offsets cluster around +-P: P = centre of the cluster that holds the largest |offset|
     int lo = maxabs, hi = maxabs;
@@ -227,17 +227,17 @@ static int plan_sweep(mk_matrix *A, const std::vector<int> &tab, const std::vect
     for (int u = 0; u < len; u++) {
       const int o = off_of(base, u);
       const int a = (o > P / 2) ? 1 : (o < -(P / 2)) ? -1 : 0;
-      E[u].a = a;
-      E[u].b = o - a * P;
+      ea[u] = a;
+      eb[u] = o - a * P;
     }
   }
   int bmin = 0, bmax = 0;
   S.diag = -1;
   for (int u = 0; u < len; u++) {
-    bmin = std::min(bmin, E[u].b);
-    bmax = std::max(bmax, E[u].b);
-    E[u].v = vals[(size_t)base * pml + u];
-    if (off_of(base, u) == 0) { S.diag = u; S.dv = E[u].v; }
+    bmin = std::min(bmin, eb[u]);
+    bmax = std::max(bmax, eb[u]);
+    ev[u] = vals[(size_t)base * pml + u];
+    if (off_of(base, u) == 0) { S.diag = u; S.dv = ev[u]; }
   }
   S.wlo = (-bmin + 1) & ~1;
   const int whi = (bmax + 1) & ~1;
@@ -250,7 +250,14 @@ static int plan_sweep(mk_matrix *A, const std::vector<int> &tab, const std::vect
   MK_TRY(dev_alloc(&A->pmask, (size_t)npat));
   MK_TRY(dev_alloc(&A->etab, 4 * 32));
   MK_HIP(hipMemcpyAsync(A->pmask, mask.data(), sizeof(unsigned) * npat, hipMemcpyHostToDevice, ctx().stream));
-  for (int cpy = 0; cpy < 4; cpy++) MK_HIP(hipMemcpyAsync(A->etab + cpy * 32, E, sizeof(E), hipMemcpyHostToDevice, ctx().stream));
+  SweepEntry E[4 * 32];
+  memset(E, 0, sizeof(E));
+  for (int c4 = 0; c4 < 4; c4++)
+    for (int u = 0; u < len; u++) {
+      E[c4 * 32 + u].off = ((((c4 + ea[u]) & 3) * S.sw) + S.wlo + eb[u]) * 8;
+      E[c4 * 32 + u].v = ev[u];
+    }
+  MK_HIP(hipMemcpyAsync(A->etab, E, sizeof(E), hipMemcpyHostToDevice, ctx().stream));
   MK_HIP(hipStreamSynchronize(ctx().stream));
   A->sweep = new SweepArgs(S);
   // default only when the grid can fill the chip: ncp chunks per plane times segments of >= 8 planes
@@ -1019,44 +1026,43 @@ __global__ __launch_bounds__(kThreads) void spmv_sweep_kernel(
   const int lid = (blockIdx.x & 7) * (nb >> 3) + (blockIdx.x >> 3);
   double acc0 = 0.0, acc1 = 0.0;
   if (lid < S.ncp * S.nseg) {
+    // all row / column indices fit 29 bits here (plan_sweep): 32-bit arithmetic throughout, one v_med3 per clamp
+    const int nr = (int)nrows;
     const int cp = lid % S.ncp, seg = lid / S.ncp;
     const int k0 = (int)((int64_t)seg * S.K / S.nseg), k1 = (int)((int64_t)(seg + 1) * S.K / S.nseg);
     const int r0 = cp * C;
     const int rows_here = min(C, S.P - r0);
     const int lr = 2 * tid;
-    const unsigned fullmask = S.len >= 32 ? 0xffffffffu : ((1u << S.len) - 1u);
     const double dvb = S.diag >= 0 ? S.dv : 0.0;
 
     // All loads that run ahead are UNCONDITIONAL (addresses clamped into the arrays instead of predicated):
     // the compiler counts outstanding loads to wait for exactly the one a step needs; a load that may or
     // may not have been issued would force it to wait for everything.  Clamped positions hold entries no
     // row refers to (their mask bit is clear) or are never read.
-    const int64_t xlast = (ncols - 1) & ~(int64_t)1;   // x[xlast], x[xlast+1]: inside the allocation (slack behind ncols)
-    const int64_t rlast = (nrows - 1) & ~(int64_t)1;
+    const int xlast = ((int)ncols - 1) & ~1;   // x[xlast], x[xlast+1]: inside the allocation (slack behind ncols)
+    const int rlast = (nr - 1) & ~1;
     auto load_slab = [&](int j, d2_t(&reg)[NL]) {   // window of plane j
-      const int64_t g0 = (int64_t)min(j, k1) * S.P + r0 - S.wlo;
+      const int g0 = min(j, k1) * S.P + r0 - S.wlo + lr;
 #pragma unroll
       for (int i = 0; i < NL; i++) {
-        const int i2 = tid + i * kThreads;
-        const int64_t g = min(max(g0 + 2 * i2, (int64_t)0), xlast);
+        const int g = min(max(g0 + i * 2 * kThreads, 0), xlast);
         reg[i] = *reinterpret_cast<const d2_t *>(reinterpret_cast<const char *>(x) + ((unsigned)g << 3));
       }
     };
     auto write_slab = [&](int slot, const d2_t(&reg)[NL]) {
+      double *dst = ring + slot * sw + lr;
 #pragma unroll
-      for (int i = 0; i < NL; i++) {
-        const int i2 = tid + i * kThreads;
-        if (2 * i2 < sw) *reinterpret_cast<d2_t *>(ring + slot * sw + 2 * i2) = reg[i];
-      }
+      for (int i = 0; i < NL; i++)
+        if (lr + i * 2 * kThreads < sw) *reinterpret_cast<d2_t *>(dst + i * 2 * kThreads) = reg[i];
     };
-    auto row_of = [&](int j) -> int64_t { return (int64_t)j * S.P + r0 + lr; };
-    auto live = [&](int j) -> bool { return j < k1 && lr < rows_here && row_of(j) < nrows; };
+    auto row_of = [&](int j) -> int { return j * S.P + r0 + lr; };
+    auto live = [&](int j) -> bool { return j < k1 && lr < rows_here && row_of(j) < nr; };
     auto load_ids = [&](int j) -> unsigned {   // pattern ids of rows g, g+1 (g even); the id behind the last row is slack
-      const int64_t g = min(row_of(j), rlast);
+      const int g = min(row_of(j), rlast);
       return *reinterpret_cast<const unsigned *>(reinterpret_cast<const char *>(pat) + ((unsigned)g << 1));
     };
     auto load_pair = [&](const double *p, int j) -> d2_t {   // p[g], p[g+1]; p[nrows] is allocation slack
-      const int64_t g = min(row_of(j), rlast);
+      const int g = min(row_of(j), rlast);
       return *reinterpret_cast<const d2_t *>(reinterpret_cast<const char *>(p) + ((unsigned)g << 3));
     };
     const double *aux = (MODE == 2) ? rhs : (MODE == 0 && beta != 0.0) ? y : nullptr;
@@ -1091,38 +1097,44 @@ __global__ __launch_bounds__(kThreads) void spmv_sweep_kernel(
     auto step = [&](int k, d2_t(&st)[NL], unsigned &idr, d2_t &axr, d2_t &exr) {
       const unsigned id0 = idr;
       const d2_t ax0 = axr, ex0 = exr;
+      const int jb = (k - k0 + 1) & (NS - 1);   // ring slot of plane k
       if (live(k)) {
-        const int64_t g = row_of(k);
-        const bool two = g + 1 < nrows;
+        const int g = row_of(k);
+        const bool two = g + 1 < nr;
         const unsigned mA = smask[id0 & 0xffffu];
         const unsigned mB = two ? smask[min(id0 >> 16, (unsigned)npat - 1u)] : 0u;
-        const int jb = k - k0 + 1;   // ring position of plane k
+        const char *wl = reinterpret_cast<const char *>(ring) + lr * 8;
         double s0 = 0.0, s1 = 0.0;
-        const bool all_full = __all((mA & mB) == fullmask);
         for (int u0 = 0; u0 < S.len; u0 += 8) {
-          // the entries come by scalar loads (two s_load_dwordx16 per batch, scalar cache).  The table is stored
-          // four times and step k reads copy k & 3, so that the compiler re-loads it per step instead of
-          // keeping all 32 entries in SGPRs for the whole kernel (it did, and spilled them: 487 v_readlane per step)
-          const SweepEntry *e = etab + (k & 3) * 32 + u0;
-          double p0[8], p1[8], vv[8];
+          // Eight entries per batch by two 64-byte scalar loads (scalar cache).  The table is stored once per
+          // ring slot with the LDS offsets of that slot already worked out, which also makes the compiler
+          // re-load it per step instead of keeping all 32 entries in SGPRs for the whole kernel (it did, and
+          // spilled them: 487 v_readlane per step).  Branch-free: a row takes entry u iff bit u of its mask
+          // is set (padding entries have no bit in any mask); the sum is SELECTED, not multiplied by 0/1.
+          typedef int i16_t __attribute__((ext_vector_type(16)));
+          const i16_t *eb = reinterpret_cast<const i16_t *>(etab + jb * 32 + u0);
+          const i16_t b0 = eb[0], b1 = eb[1];
+          int off[8];
+          double vv[8];
+#define MK_ENT(U, B, Q)                                                                                   \
+  off[U] = B[4 * Q];                                                                                      \
+  vv[U] = __longlong_as_double((long long)(((unsigned long long)(unsigned)B[4 * Q + 3] << 32) | (unsigned)B[4 * Q + 2]));
+          MK_ENT(0, b0, 0) MK_ENT(1, b0, 1) MK_ENT(2, b0, 2) MK_ENT(3, b0, 3)
+          MK_ENT(4, b1, 0) MK_ENT(5, b1, 1) MK_ENT(6, b1, 2) MK_ENT(7, b1, 3)
+#undef MK_ENT
+          double p0[8], p1[8];
 #pragma unroll
           for (int u = 0; u < 8; u++) {
-            const double *w = ring + ((jb + e[u].a) & (NS - 1)) * sw + (S.wlo + e[u].b) + lr;
+            const double *w = reinterpret_cast<const double *>(wl + off[u]);
             p0[u] = w[0];
             p1[u] = w[1];
-            vv[u] = e[u].v;
           }
-          if (all_full) {
+          const unsigned ka = mA >> u0, kb = mB >> u0;
 #pragma unroll
-            for (int u = 0; u < 8; u++)
-              if (u0 + u < S.len) { s0 += vv[u] * p0[u]; s1 += vv[u] * p1[u]; }
-          } else {
-#pragma unroll
-            for (int u = 0; u < 8; u++)
-              if (u0 + u < S.len) {
-                if ((mA >> (u0 + u)) & 1u) s0 += vv[u] * p0[u];
-                if ((mB >> (u0 + u)) & 1u) s1 += vv[u] * p1[u];
-              }
+          for (int u = 0; u < 8; u++) {
+            const double t0 = s0 + vv[u] * p0[u], t1 = s1 + vv[u] * p1[u];
+            s0 = ((ka >> u) & 1u) ? t0 : s0;
+            s1 = ((kb >> u) & 1u) ? t1 : s1;
           }
         }
         d2_t out;
@@ -1130,7 +1142,7 @@ __global__ __launch_bounds__(kThreads) void spmv_sweep_kernel(
           out.x = (beta == 0.0) ? alpha * s0 : alpha * s0 + beta * ax0.x;
           out.y = (beta == 0.0) ? alpha * s1 : alpha * s1 + beta * ax0.y;
         } else {
-          const double *wc = ring + (jb & (NS - 1)) * sw + S.wlo + lr;   // x[g], x[g+1]
+          const double *wc = reinterpret_cast<const double *>(wl) + jb * sw + S.wlo;   // x[g], x[g+1]
           const double xa = wc[0], xb = wc[1];
           if (MODE == 2) {
             const double ra = (ax0.x - ex0.x) - s0, rb = (ax0.y - ex0.y) - s1;
