@@ -82,6 +82,19 @@ struct SweepEntry {   // one entry of the base pattern.  Device table: 4 copies 
   double v;
 };
 
+// solver state of the fused CG iteration, one record in device memory (krylov_kernels.h, spmv.hip)
+struct PcgState {
+  double gamma, gamma_old, alpha, pp, i_prod, bi_prod, eps, sdotp;
+  long long iter;
+  int done;        // 0 running, 1 converged, 2 breakdown
+  int converged;
+  int breakdown;   // 1 zero <s,p>, 2 subnormal alpha, 3 subnormal gamma
+  // fused-sweep variant only (x is updated one kernel later there):
+  int pending;     // stop code raised by the kernel that still had to finish its x update; the next kernel makes it `done`
+  int cand;        // residual test passed, the relative-change test waits for <x,x> of the update in flight
+  int pad;
+};
+
 // ---------------------------------------------------------------------------- objects
 }  // namespace mk
 
@@ -129,7 +142,7 @@ struct mk_matrix {
   unsigned *pmask = nullptr;       // device, npat: which entries of the base pattern each pattern keeps
   mk::SweepEntry *etab = nullptr;  // device, 32 entries
   bool sweep_auto = false;         // enough parallelism for the sweep kernel to be the default
-  mutable int sweep_bpc[3] = {0, 0, 0};
+  mutable int sweep_bpc[5] = {0, 0, 0, 0, 0};
   int npat = 0, pml = 0;
   int max_off = 0;                 // largest |column - row| over all patterns
   // split kernel: chunk c covers entries [c*kSplitChunk, (c+1)*kSplitChunk); chunk_row[c] = first row starting in it
@@ -162,6 +175,14 @@ int launch_spmv_dot(const mk_matrix *A, const double *x, double *y, double *slab
 // MK_ERR_UNSUPPORTED (no error text) when A is not served by the stream kernel
 int launch_jacobi_sweep(const mk_matrix *A, const double *rhs, const double *extra, const double *xold, double *xnew,
                         double *slab, const int *done, int *nblocks);
+
+// fused CG on matrices served by the sweep kernel (two more modes of it; the scalar logic of the step runs in
+// their prologues).  dots: partials of <A p, p>, <p,p> into slab_out, nothing stored; first settles a pending
+// relative-change test from slab_xx.  resid: r -= alpha * A p with alpha from slab_in, partials of <r,z>, <r,r>.
+int launch_sweep_cg_dots(const mk_matrix *A, const double *p, double *slab_out, PcgState *st, const double *slab_xx,
+                         int nblocks_xx, int *nblocks);
+int launch_sweep_cg_resid(const mk_matrix *A, const double *p, double *r, const double *dinv, const double *slab_in,
+                          int nblocks_in, double *slab_out, PcgState *st, int *nblocks);
 
 int exclusive_scan_u32(const uint32_t *in, uint32_t *out, size_t n, uint32_t *total_out_dev);
 

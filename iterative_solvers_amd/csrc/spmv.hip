@@ -11,6 +11,8 @@
 //                   span.  Used for short, regular rows (stencils, banded).
 //   stream kernel : nnz-balanced chunks staged through LDS, rows split inside the chunk;
 //                   rows longer than a chunk are split over blocks (skewed / power-law rows).
+#include <cfloat>
+
 #include "mk_internal.h"
 
 namespace mk {
@@ -1013,7 +1015,12 @@ template <int MODE, int NL>   // NL = 16-byte loads per thread per slab = ceil(s
 __global__ __launch_bounds__(kThreads) void spmv_sweep_kernel(
     const SweepArgs S, const SweepEntry *__restrict__ etab, int64_t nrows, int64_t ncols, const unsigned short *__restrict__ pat,
     const unsigned *__restrict__ pmask, int npat, const double *__restrict__ x, double *__restrict__ y, double alpha, double beta, double *__restrict__ slab,
-    const int *__restrict__ done, const double *__restrict__ rhs, const double *__restrict__ extra) {
+    const int *__restrict__ done, const double *__restrict__ rhs, const double *__restrict__ extra,
+    PcgState *st, const double *__restrict__ slab_in, int nblocks_in) {
+  // MODE 0: y = alpha A x + beta y.  1: y = A x, partials of <y,x>, <x,x>.  2: Jacobi sweep.
+  // MODE 3 (fused CG, first kernel of a step): partials of <A x, x>, <x,x> only, nothing stored.
+  // MODE 4 (second kernel): rhs (= y = the residual r) <- r - alpha A x with alpha = gamma / <A x, x> from slab_in;
+  //                         partials of <r,z>, <r,r>; `extra` = 1/diag when the Jacobi preconditioner is on.
   if (done != nullptr && *done != 0) return;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   constexpr int C = kSweepC, NS = kSweepNS;
@@ -1021,6 +1028,48 @@ __global__ __launch_bounds__(kThreads) void spmv_sweep_kernel(
   double *ring = reinterpret_cast<double *>(smem_raw);            // NS slabs of sw entries
   unsigned *smask = reinterpret_cast<unsigned *>(ring + NS * sw);   // npat
   const int tid = threadIdx.x;
+  if (MODE == 3 || MODE == 4) {
+    const bool leader = (blockIdx.x == 0 && tid == 0);
+    if (st->done != 0) return;
+    if (st->pending != 0) {   // the previous kernel finished its x update and asked to stop
+      if (leader) st->done = st->pending;
+      return;
+    }
+    if (MODE == 3) {
+      const int cand = st->cand;
+      if (cand != 0) {   // settle the relative-change test with <x,x> of the update that has just landed
+        double v[1];
+        reduce_slab<1, kThreads>(slab_in, nblocks_in, kSlabStride, v, ring);
+        const double ratio = st->alpha * st->alpha * st->pp / v[0];
+        __syncthreads();   // every thread has read the state before the leader touches it
+        if (ratio < st->eps) {
+          if (leader) { st->converged = 1; st->done = 1; st->cand = 0; }
+          return;
+        }
+        if (cand == 2) {
+          if (leader) { st->breakdown = 3; st->done = 2; st->cand = 0; }
+          return;
+        }
+        if (leader) st->cand = 0;
+      }
+    } else {
+      double d[2];
+      reduce_slab<2, kThreads>(slab_in, nblocks_in, kSlabStride, d, ring);
+      const double sdotp = d[0], gamma = st->gamma;
+      __syncthreads();
+      if (sdotp == 0.0) {
+        if (leader) { st->iter += 1; st->breakdown = 1; st->done = 2; }
+        return;
+      }
+      alpha = gamma / sdotp;
+      if (!(alpha > DBL_MIN)) {
+        if (leader) { st->iter += 1; st->breakdown = 2; st->done = 2; }
+        return;
+      }
+      if (leader) { st->alpha = alpha; st->gamma_old = gamma; st->pp = d[1]; st->sdotp = sdotp; st->iter += 1; }
+    }
+    __syncthreads();   // ring was reduction scratch
+  }
   for (int i = tid; i < npat; i += kThreads) smask[i] = pmask[i];
   const int nb = gridDim.x;   // multiple of 8; blocks of one XCD take neighbouring chunks of a plane (shared halos in its L2)
   const int lid = (blockIdx.x & 7) * (nb >> 3) + (blockIdx.x >> 3);
@@ -1065,7 +1114,8 @@ __global__ __launch_bounds__(kThreads) void spmv_sweep_kernel(
       const int g = min(row_of(j), rlast);
       return *reinterpret_cast<const d2_t *>(reinterpret_cast<const char *>(p) + ((unsigned)g << 3));
     };
-    const double *aux = (MODE == 2) ? rhs : (MODE == 0 && beta != 0.0) ? y : nullptr;
+    const double *aux = (MODE == 2 || MODE == 4) ? rhs : (MODE == 0 && beta != 0.0) ? y : nullptr;
+    constexpr bool kExtra = (MODE == 2 || MODE == 4);
 
     // Three register stages, each used in place: stage (k mod 3) holds slab k+2 at step k, is written to the
     // ring and at once re-loaded with slab k+5 -- no register-to-register rotation (a move of a register
@@ -1082,15 +1132,15 @@ __global__ __launch_bounds__(kThreads) void spmv_sweep_kernel(
     d2_t ax0 = {0.0, 0.0}, ax1 = ax0, ax2 = ax0, ex0 = ax0, ex1 = ax0, ex2 = ax0;
     unsigned id0 = load_ids(k0);
     if (aux) ax0 = load_pair(aux, k0);
-    if (MODE == 2 && extra) ex0 = load_pair(extra, k0);
+    if (kExtra && extra) ex0 = load_pair(extra, k0);
     load_slab(k0 + 2, st0);
     unsigned id1 = load_ids(k0 + 1);
     if (aux) ax1 = load_pair(aux, k0 + 1);
-    if (MODE == 2 && extra) ex1 = load_pair(extra, k0 + 1);
+    if (kExtra && extra) ex1 = load_pair(extra, k0 + 1);
     load_slab(k0 + 3, st1);
     unsigned id2 = load_ids(k0 + 2);
     if (aux) ax2 = load_pair(aux, k0 + 2);
-    if (MODE == 2 && extra) ex2 = load_pair(extra, k0 + 2);
+    if (kExtra && extra) ex2 = load_pair(extra, k0 + 2);
     load_slab(k0 + 4, st2);
     __syncthreads();
 
@@ -1152,6 +1202,16 @@ __global__ __launch_bounds__(kThreads) void spmv_sweep_kernel(
             out.y = xb + rb / db;
             acc0 += ra * ra;
             if (two) acc0 += rb * rb;
+          } else if (MODE == 4) {
+            double ra = ax0.x, rb = ax0.y;
+            ra -= alpha * s0;
+            rb -= alpha * s1;
+            out.x = ra;
+            out.y = rb;
+            const double za = extra ? ra * ex0.x : ra, zb = extra ? rb * ex0.y : rb;
+            acc0 += ra * za;
+            acc1 += ra * ra;
+            if (two) { acc0 += rb * zb; acc1 += rb * rb; }
           } else {
             out.x = s0;
             out.y = s1;
@@ -1160,15 +1220,17 @@ __global__ __launch_bounds__(kThreads) void spmv_sweep_kernel(
             if (two) { acc0 += s1 * xb; acc1 += xb * xb; }
           }
         }
-        if (two) *reinterpret_cast<d2_t *>(reinterpret_cast<char *>(y) + ((unsigned)g << 3)) = out;
-        else *reinterpret_cast<double *>(reinterpret_cast<char *>(y) + ((unsigned)g << 3)) = out.x;
+        if (MODE != 3) {
+          if (two) *reinterpret_cast<d2_t *>(reinterpret_cast<char *>(y) + ((unsigned)g << 3)) = out;
+          else *reinterpret_cast<double *>(reinterpret_cast<char *>(y) + ((unsigned)g << 3)) = out.x;
+        }
       }
       // slab k+2 (loaded three steps ago) into the slot plane k-2 occupied; nobody reads that slot in this step
       write_slab((k - k0 + 3) & (NS - 1), st);
       // look-ahead loads into the registers just consumed: ids / aux of plane k+3, slab k+5
       idr = load_ids(k + 3);
       if (aux) axr = load_pair(aux, k + 3);
-      if (MODE == 2 && extra) exr = load_pair(extra, k + 3);
+      if (kExtra && extra) exr = load_pair(extra, k + 3);
       load_slab(k + 5, st);
       __syncthreads();
     };
@@ -1184,14 +1246,15 @@ __global__ __launch_bounds__(kThreads) void spmv_sweep_kernel(
     block_sum<2, kThreads>(w, ring);
     if (threadIdx.x == 0) {
       slab[0 * kSlabStride + blockIdx.x] = w[0];
-      if (MODE == 1) slab[1 * kSlabStride + blockIdx.x] = w[1];
+      if (MODE != 2) slab[1 * kSlabStride + blockIdx.x] = w[1];
     }
   }
 }
 
 template <int MODE>
 static int launch_sweep(const mk_matrix *A, double alpha, const double *x, double beta, double *y, double *slab,
-                        const int *done, int *nblocks, const double *rhs = nullptr, const double *extra = nullptr) {
+                        const int *done, int *nblocks, const double *rhs = nullptr, const double *extra = nullptr,
+                        PcgState *st = nullptr, const double *slab_in = nullptr, int nblocks_in = 0) {
   Context &c = ctx();
   if (!A->sweep) return fail(MK_ERR_UNSUPPORTED, "spmv: the sweep kernel needs rows that are sub-lists of one pattern with offsets a*P + b");
   SweepArgs S = *A->sweep;
@@ -1220,7 +1283,8 @@ static int launch_sweep(const mk_matrix *A, double alpha, const double *x, doubl
 #define MK_LAUNCH_SW(NLL)                                                                                                  \
   case NLL:                                                                                                                \
     hipLaunchKernelGGL((spmv_sweep_kernel<MODE, NLL>), dim3((unsigned)blocks), dim3(kThreads), lds, c.stream, S, A->etab, A->nrows, \
-                       A->ncols, A->pat, A->pmask, A->npat, x, y, alpha, beta, slab, done, rhs, extra);                    \
+                       A->ncols, A->pat, A->pmask, A->npat, x, y, alpha, beta, slab, done, rhs, extra, st, slab_in,       \
+                       nblocks_in);                                                                                        \
     break;
   switch (nl) {
     MK_LAUNCH_SW(2)
@@ -1421,6 +1485,16 @@ int launch_jacobi_sweep(const mk_matrix *A, const double *rhs, const double *ext
   if (A->kernel == MK_SPMV_PATTERN) return launch_pattern<2>(A, 1.0, xold, 0.0, xnew, slab, done, nblocks, rhs, extra);
   if (A->kernel != MK_SPMV_STREAM) return MK_ERR_UNSUPPORTED;
   return launch_stream<2>(A, 1.0, xold, 0.0, xnew, slab, done, nblocks, rhs, extra);
+}
+
+int launch_sweep_cg_dots(const mk_matrix *A, const double *p, double *slab_out, PcgState *st, const double *slab_xx,
+                         int nblocks_xx, int *nblocks) {
+  return launch_sweep<3>(A, 1.0, p, 0.0, nullptr, slab_out, nullptr, nblocks, nullptr, nullptr, st, slab_xx, nblocks_xx);
+}
+
+int launch_sweep_cg_resid(const mk_matrix *A, const double *p, double *r, const double *dinv, const double *slab_in,
+                          int nblocks_in, double *slab_out, PcgState *st, int *nblocks) {
+  return launch_sweep<4>(A, 0.0, p, 0.0, r, slab_out, nullptr, nblocks, r, dinv, st, slab_in, nblocks_in);
 }
 
 int launch_spmv_dot(const mk_matrix *A, const double *x, double *y, double *slab, const int *done, int *nblocks) {
