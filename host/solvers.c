@@ -43,6 +43,7 @@ static void usage(const char *argv0) {
   printf("  -niter <n>             : solve problem n times (later solves start from the previous x)\n");
   printf("  -dev <id>              : GPU to use (default 0)\n");
   printf("  -solver <ID>           : solver ID\n");
+  printf("                           6  - BiCGSTAB\n");
   printf("                           50 - PCG\n");
   printf("                           51 - PCG + diagonal scaling\n");
   printf("                           70 - Jacobi iteration\n");
@@ -77,9 +78,9 @@ int main(int argc, char *argv[]) {
     else i += 1;                                                      /* unknown flags are skipped (:149-151) */
   }
   if (!mtx) { usage(argv[0]); return 1; }
-  if (solver_id != 50 && solver_id != 51 && solver_id != 70) {
+  if (solver_id != 6 && solver_id != 50 && solver_id != 51 && solver_id != 70) {
     printf("Invalid solver id specified.\n");
-    fprintf(stderr, "solver %d is a HYPRE preconditioner/solver stack outside this library; use 50, 51 or 70\n", solver_id);
+    fprintf(stderr, "solver %d is a HYPRE preconditioner/solver stack outside this library; use 6, 50, 51 or 70\n", solver_id);
     return 1;
   }
 
@@ -176,6 +177,24 @@ int main(int argc, char *argv[]) {
     CK(mk_pcg_get_num_iterations(solver, &num_iterations));           /* :765 */
     CK(mk_pcg_get_final_relative_residual_norm(solver, &final_res_norm)); /* :766 */
     CK(mk_pcg_destroy(solver));                                       /* :775 */
+  } else if (solver_id == 6) {
+    mk_bicgstab *solver = NULL;
+    CK(mk_bicgstab_create(&solver));                                  /* :524 */
+    CK(mk_bicgstab_set_print_level(solver, prnt_info));               /* :527 */
+    CK(mk_bicgstab_set_logging(solver, 1));                           /* :529 */
+    CK(mk_bicgstab_set_tol(solver, tol));                             /* :532 */
+    CK(mk_bicgstab_set_max_iter(solver, maxit));                      /* :533 */
+    CK(mk_bicgstab_setup(solver, A, b, x));                           /* :536 */
+    CK(mk_synchronize());
+    double t = -now_s();                                              /* :540 */
+    for (int i = 0; i < niter; i++) CK(mk_bicgstab_solve(solver, A, b, x)); /* :541-542 */
+    CK(mk_synchronize());
+    t += now_s();
+    walltime = t;
+    printf("\nParCSRBiCGSTABC Solve time = %f seconds\n\n", walltime); /* :550, the reference's spelling */
+    CK(mk_bicgstab_get_num_iterations(solver, &num_iterations));      /* :553 */
+    CK(mk_bicgstab_get_final_relative_residual_norm(solver, &final_res_norm)); /* :554 */
+    CK(mk_bicgstab_destroy(solver));                                  /* :563 */
   } else {
     mk_jacobi *solver = NULL;
     CK(mk_jacobi_create(&solver));

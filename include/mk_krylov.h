@@ -65,6 +65,7 @@ typedef struct mk_matrix mk_matrix;   /* stands in for HYPRE_IJMatrix / HYPRE_Pa
 typedef struct mk_vector mk_vector;   /* HYPRE_IJVector / HYPRE_ParVector (solvers.c:57-60) */
 typedef struct mk_coo mk_coo;         /* a COO matrix resident in device memory */
 typedef struct mk_pcg mk_pcg;         /* HYPRE_Solver for PCG (solvers.c:65,729) */
+typedef struct mk_bicgstab mk_bicgstab;   /* HYPRE_Solver for BiCGSTAB (solvers.c:65,524) */
 typedef struct mk_jacobi mk_jacobi;   /* extension: plain Jacobi iteration (no reference counterpart) */
 
 /* ---- life cycle: HYPRE_Init() / HYPRE_Finalize() (solvers.c:79,1560) ------------------- */
@@ -171,6 +172,26 @@ int mk_pcg_get_converged(const mk_pcg *solver, int *converged, int *breakdown);
 /* relative residual norms 0..iterations (needs logging>0); returns how many were written */
 int mk_pcg_get_residual_history(const mk_pcg *solver, double *norms, int capacity);
 int mk_pcg_destroy(mk_pcg *solver);                               /* HYPRE_ParCSRPCGDestroy :775 */
+
+/* ---- BiCGSTAB, solver id 6 (solvers.c:517-564), identity preconditioner -------------------
+ * HYPRE_ParCSRBiCGSTABCreate :524, SetPrintLevel :527, SetLogging :529, SetTol :532, SetMaxIter :533,
+ * Setup :536, Solve :542, GetNumIterations :553, GetFinalRelativeResidualNorm :554, Destroy :563.
+ * Stops when ||r|| <= tol * ||b|| holds for the recomputed residual b - A x as well (hypre's rule);
+ * breakdown: 1 <r0,Ap> ~ 0, 2 <r0,r> ~ 0, 3 gamma ~ 0 (|.| < 1e-128). */
+int mk_bicgstab_create(mk_bicgstab **solver);
+int mk_bicgstab_set_max_iter(mk_bicgstab *solver, int max_iter);
+int mk_bicgstab_set_tol(mk_bicgstab *solver, double tol);
+int mk_bicgstab_set_print_level(mk_bicgstab *solver, int level);
+int mk_bicgstab_set_logging(mk_bicgstab *solver, int logging);
+int mk_bicgstab_set_check_every(mk_bicgstab *solver, int iterations);   /* host polls the device stop flag this often */
+int mk_bicgstab_setup(mk_bicgstab *solver, const mk_matrix *A, const mk_vector *b, const mk_vector *x);
+int mk_bicgstab_solve(mk_bicgstab *solver, const mk_matrix *A, const mk_vector *b, mk_vector *x);
+int mk_bicgstab_get_num_iterations(const mk_bicgstab *solver, long long *iterations);
+int mk_bicgstab_get_final_relative_residual_norm(const mk_bicgstab *solver, double *norm);
+int mk_bicgstab_get_converged(const mk_bicgstab *solver, int *converged, int *breakdown);
+/* absolute ||r|| after each iteration (needs logging > 0 at setup); returns the number of entries written */
+int mk_bicgstab_get_residual_history(const mk_bicgstab *solver, double *norms, int capacity);
+int mk_bicgstab_destroy(mk_bicgstab *solver);
 
 /* ---- plain Jacobi iteration, extension solver id 70 --------------- */
 int mk_jacobi_create(mk_jacobi **solver);

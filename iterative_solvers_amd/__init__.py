@@ -56,6 +56,10 @@ EXPORTS = [
     "mk_pcg_set_check_every", "mk_pcg_setup", "mk_pcg_solve", "mk_pcg_get_num_iterations",
     "mk_pcg_get_final_relative_residual_norm", "mk_pcg_get_converged",
     "mk_pcg_get_residual_history", "mk_pcg_destroy",
+    "mk_bicgstab_create", "mk_bicgstab_set_max_iter", "mk_bicgstab_set_tol", "mk_bicgstab_set_print_level",
+    "mk_bicgstab_set_logging", "mk_bicgstab_set_check_every", "mk_bicgstab_setup", "mk_bicgstab_solve",
+    "mk_bicgstab_get_num_iterations", "mk_bicgstab_get_final_relative_residual_norm", "mk_bicgstab_get_converged",
+    "mk_bicgstab_get_residual_history", "mk_bicgstab_destroy",
     "mk_jacobi_create", "mk_jacobi_set_max_iter", "mk_jacobi_set_tol", "mk_jacobi_set_check_every",
     "mk_jacobi_setup", "mk_jacobi_solve", "mk_jacobi_get_num_iterations",
     "mk_jacobi_get_final_relative_residual_norm", "mk_jacobi_get_converged", "mk_jacobi_destroy",
@@ -112,6 +116,14 @@ def load():
         "mk_pcg_get_final_relative_residual_norm": [P, C.POINTER(C.c_double)],
         "mk_pcg_get_converged": [P, C.POINTER(C.c_int), C.POINTER(C.c_int)],
         "mk_pcg_get_residual_history": [P, P, C.c_int], "mk_pcg_destroy": [P],
+        "mk_bicgstab_create": [C.POINTER(P)], "mk_bicgstab_set_max_iter": [P, C.c_int], "mk_bicgstab_set_tol": [P, C.c_double],
+        "mk_bicgstab_set_print_level": [P, C.c_int], "mk_bicgstab_set_logging": [P, C.c_int],
+        "mk_bicgstab_set_check_every": [P, C.c_int],
+        "mk_bicgstab_setup": [P, P, P, P], "mk_bicgstab_solve": [P, P, P, P],
+        "mk_bicgstab_get_num_iterations": [P, C.POINTER(C.c_longlong)],
+        "mk_bicgstab_get_final_relative_residual_norm": [P, C.POINTER(C.c_double)],
+        "mk_bicgstab_get_converged": [P, C.POINTER(C.c_int), C.POINTER(C.c_int)],
+        "mk_bicgstab_get_residual_history": [P, P, C.c_int], "mk_bicgstab_destroy": [P],
         "mk_jacobi_create": [C.POINTER(P)], "mk_jacobi_set_max_iter": [P, C.c_int],
         "mk_jacobi_set_tol": [P, C.c_double], "mk_jacobi_set_check_every": [P, C.c_int],
         "mk_jacobi_setup": [P, P, P, P], "mk_jacobi_solve": [P, P, P, P],
@@ -389,6 +401,43 @@ class PCG:
     def __del__(self):
         if getattr(self, "h", None) and _lib is not None:
             _lib.mk_pcg_destroy(self.h)
+            self.h = None
+
+
+class BiCGSTAB:
+    """HYPRE_ParCSRBiCGSTAB* life cycle as solvers.c:517-564 drives it (solver id 6)"""
+
+    def __init__(self, max_iter=1000, tol=1e-6, logging=1, print_level=0, check_every=16):
+        init()
+        self.h = C.c_void_p()
+        L = load()
+        _ck(L.mk_bicgstab_create(C.byref(self.h)))
+        _ck(L.mk_bicgstab_set_max_iter(self.h, max_iter))
+        _ck(L.mk_bicgstab_set_tol(self.h, tol))
+        _ck(L.mk_bicgstab_set_print_level(self.h, print_level))
+        _ck(L.mk_bicgstab_set_logging(self.h, logging))
+        _ck(L.mk_bicgstab_set_check_every(self.h, check_every))
+
+    def setup(self, A, b, x):
+        _ck(load().mk_bicgstab_setup(self.h, A.h, b.h, x.h))
+
+    def solve(self, A, b, x):
+        L = load()
+        _ck(L.mk_bicgstab_solve(self.h, A.h, b.h, x.h))
+        it, nrm, cv, bd = C.c_longlong(), C.c_double(), C.c_int(), C.c_int()
+        _ck(L.mk_bicgstab_get_num_iterations(self.h, C.byref(it)))
+        _ck(L.mk_bicgstab_get_final_relative_residual_norm(self.h, C.byref(nrm)))
+        _ck(L.mk_bicgstab_get_converged(self.h, C.byref(cv), C.byref(bd)))
+        return dict(iterations=it.value, rel_res_norm=nrm.value, converged=cv.value, breakdown=bd.value)
+
+    def residual_history(self, capacity):
+        out = np.empty(capacity)
+        n = _ck(load().mk_bicgstab_get_residual_history(self.h, out.ctypes.data, capacity))
+        return out[:n]
+
+    def __del__(self):
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.mk_bicgstab_destroy(self.h)
             self.h = None
 
 

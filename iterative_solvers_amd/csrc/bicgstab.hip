@@ -1,0 +1,358 @@
+// bicgstab.hip -- BiCGSTAB on one GPU.
+//
+// Stands in for HYPRE_ParCSRBiCGSTABSetup/Solve as the reference drives them for solver id 6
+// (solvers.c:517-564: PrintLevel, Logging, Tol, MaxIter, identity preconditioner).
+// hypre_BiCGSTABSolve is not in /root/reference; the loop follows its published algorithm
+// (oracle/oracle.c orc_bicgstab lists the steps).  PARITY UNPINNED.
+//
+// Per iteration: two SpMVs (any of the kernels of spmv.hip), five vector kernels, and two
+// conditional kernels that only run when the recursive residual passes the test (HYPRE then
+// recomputes r = b - A x and tests again).  All scalars (alpha, gamma, beta, norms, flags) live
+// in a device record; every reduction is finished in the next kernel's prologue from a slab of
+// per-block partials (fixed order, no atomics); the host polls the stop flag every check_every
+// iterations.  Algorithmic bytes per iteration: 2 SpMV + 168 n.
+#include <cfloat>
+#include <cmath>
+
+#include "krylov_kernels.h"
+
+namespace mk {
+
+struct BicgState {
+  double res, alpha, gamma, r_norm, b_norm, eps;
+  long long iter;
+  int done;        // 0 running, 1 converged, 2 breakdown
+  int converged;
+  int breakdown;   // 1 <r0,q> ~ 0, 2 res ~ 0, 3 gamma ~ 0
+  int skip_true;   // 1: the true-residual kernels of this iteration return at once
+};
+
+constexpr double kEpsMac = 1.e-128;
+
+// partials of <a1,b1> (component 0) and, when a2 != null, <a2,b2> (component 1)
+static __global__ __launch_bounds__(kVecThreads) void dot2_kernel(int64_t n, const double *__restrict__ a1, const double *__restrict__ b1,
+                                                                  const double *__restrict__ a2, const double *__restrict__ b2,
+                                                                  double *__restrict__ slab, const int *__restrict__ done) {
+  if (done != nullptr && *done != 0) return;
+  double v[2] = {0.0, 0.0};
+  for (int64_t i = (int64_t)blockIdx.x * kVecThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kVecThreads) {
+    v[0] += a1[i] * b1[i];
+    if (a2) v[1] += a2[i] * b2[i];
+  }
+  __shared__ double smem[2 * (kVecThreads / 64)];
+  block_sum<2, kVecThreads>(v, smem);
+  if (threadIdx.x == 0) {
+    slab[blockIdx.x] = v[0];
+    slab[kSlabStride + blockIdx.x] = v[1];
+  }
+}
+
+// after r0 = b - A x: r = p = r0, partials of <b,b>, <r0,r0>
+static __global__ __launch_bounds__(kVecThreads) void bicg_init_vectors_kernel(int64_t n, const double *__restrict__ b, const double *__restrict__ r0,
+                                                                               double *__restrict__ r, double *__restrict__ p, double *__restrict__ slab) {
+  double v[2] = {0.0, 0.0};
+  for (int64_t i = (int64_t)blockIdx.x * kVecThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kVecThreads) {
+    const double bi = b[i], ri = r0[i];
+    r[i] = ri;
+    p[i] = ri;
+    v[0] += bi * bi;
+    v[1] += ri * ri;
+  }
+  __shared__ double smem[2 * (kVecThreads / 64)];
+  block_sum<2, kVecThreads>(v, smem);
+  if (threadIdx.x == 0) {
+    slab[blockIdx.x] = v[0];
+    slab[kSlabStride + blockIdx.x] = v[1];
+  }
+}
+
+static __global__ __launch_bounds__(kVecThreads) void bicg_init_scalars_kernel(const double *slab, int nblocks, double tol, BicgState *st, double *norms) {
+  __shared__ double smem[2 * (kVecThreads / 64)];
+  double v[2];
+  reduce_slab<2, kVecThreads>(slab, nblocks, kSlabStride, v, smem);
+  if (threadIdx.x == 0) {
+    BicgState s;
+    memset(&s, 0, sizeof(s));
+    s.b_norm = sqrt(v[0]);
+    s.res = v[1];
+    s.r_norm = sqrt(v[1]);
+    s.eps = tol * (s.b_norm > 0.0 ? s.b_norm : s.r_norm);
+    s.done = (s.r_norm == 0.0) ? 1 : 0;   // hypre returns at once, zero iterations
+    s.skip_true = 1;
+    *st = s;
+    if (norms) norms[0] = s.r_norm;
+  }
+}
+
+// alpha = res / <r0,q>;  x += alpha p;  r -= alpha q
+static __global__ __launch_bounds__(kVecThreads) void bicg_step1_kernel(int64_t n, const double *__restrict__ p, const double *__restrict__ q,
+                                                                        double *__restrict__ x, double *__restrict__ r,
+                                                                        const double *__restrict__ slab_in, int nblocks_in, BicgState *st) {
+  if (st->done != 0) return;
+  __shared__ double smem[kVecThreads / 64];
+  double d[1];
+  reduce_slab<1, kVecThreads>(slab_in, nblocks_in, kSlabStride, d, smem);
+  const double temp = d[0], res = st->res;
+  const bool leader = (blockIdx.x == 0 && threadIdx.x == 0);
+  if (!(fabs(temp) >= kEpsMac)) {
+    if (leader) { st->iter += 1; st->breakdown = 1; st->done = 2; }
+    return;
+  }
+  const double alpha = res / temp;
+  for (int64_t i = (int64_t)blockIdx.x * kVecThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kVecThreads) {
+    x[i] += alpha * p[i];
+    r[i] -= alpha * q[i];
+  }
+  if (leader) { st->alpha = alpha; st->iter += 1; }
+}
+
+// gamma = <r,s>/<s,s> (0/0 := 0);  x += gamma r;  r -= gamma s;  partial of <r,r>
+static __global__ __launch_bounds__(kVecThreads) void bicg_step2_kernel(int64_t n, const double *__restrict__ s, double *__restrict__ x,
+                                                                        double *__restrict__ r, const double *__restrict__ slab_in,
+                                                                        int nblocks_in, double *__restrict__ slab_out, BicgState *st) {
+  if (st->done != 0) return;
+  __shared__ double smem[2 * (kVecThreads / 64)];
+  double d[2];
+  reduce_slab<2, kVecThreads>(slab_in, nblocks_in, kSlabStride, d, smem);
+  const double gamma = (d[0] == 0.0 && d[1] == 0.0) ? 0.0 : d[0] / d[1];
+  double v[2] = {0.0, 0.0};
+  for (int64_t i = (int64_t)blockIdx.x * kVecThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kVecThreads) {
+    double ri = r[i];
+    x[i] += gamma * ri;
+    ri -= gamma * s[i];
+    r[i] = ri;
+    v[0] += ri * ri;
+  }
+  block_sum<2, kVecThreads>(v, smem);
+  if (threadIdx.x == 0) slab_out[blockIdx.x] = v[0];
+  if (blockIdx.x == 0 && threadIdx.x == 0) st->gamma = gamma;
+}
+
+// ||r|| of the recursive residual; decides whether the true residual has to be formed
+static __global__ __launch_bounds__(kVecThreads) void bicg_norm_kernel(const double *slab, int nblocks, BicgState *st, double *norms) {
+  if (st->done != 0) return;
+  __shared__ double smem[kVecThreads / 64];
+  double v[1];
+  reduce_slab<1, kVecThreads>(slab, nblocks, kSlabStride, v, smem);
+  if (threadIdx.x == 0) {
+    const double rn = sqrt(v[0]);
+    st->r_norm = rn;
+    if (norms) norms[st->iter] = rn;
+    st->skip_true = (rn <= st->eps) ? 0 : 1;
+  }
+}
+
+static __global__ void copy_unless_kernel(double *__restrict__ dst, const double *__restrict__ src, int64_t n, const int *__restrict__ skip) {
+  if (*skip != 0) return;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+// slab_in: <r0,r>, <r,r> of the residual as it stands now (replaced by b - A x if it was a candidate).
+// Convergence on the true residual; beta = (<r0,r>/res)(alpha/gamma); p = beta (p - gamma q) + r
+static __global__ __launch_bounds__(kVecThreads) void bicg_step3_kernel(int64_t n, const double *__restrict__ r, const double *__restrict__ q,
+                                                                        double *__restrict__ p, const double *__restrict__ slab_in,
+                                                                        int nblocks_in, BicgState *st) {
+  if (st->done != 0) return;
+  __shared__ double smem[2 * (kVecThreads / 64)];
+  double d[2];
+  reduce_slab<2, kVecThreads>(slab_in, nblocks_in, kSlabStride, d, smem);
+  const bool leader = (blockIdx.x == 0 && threadIdx.x == 0);
+  const bool cand = (st->skip_true == 0);
+  const double res_old = st->res, alpha = st->alpha, gamma = st->gamma, eps = st->eps;
+  __syncthreads();   // all threads hold the state before the leader rewrites it
+  if (cand) {
+    const double rn = sqrt(d[1]);
+    if (leader) st->r_norm = rn;
+    if (rn <= eps) {
+      if (leader) { st->converged = 1; st->done = 1; st->skip_true = 1; }
+      return;
+    }
+  }
+  if (!(fabs(res_old) >= kEpsMac)) {
+    if (leader) { st->breakdown = 2; st->done = 2; }
+    return;
+  }
+  double beta = 1.0 / res_old;
+  const double res = d[0];
+  beta *= res;
+  beta *= alpha;
+  if (!(fabs(gamma) >= kEpsMac)) {
+    if (leader) { st->res = res; st->breakdown = 3; st->done = 2; }
+    return;
+  }
+  beta /= gamma;
+  for (int64_t i = (int64_t)blockIdx.x * kVecThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kVecThreads) {
+    double t = p[i] + (-gamma) * q[i];
+    t = beta * t;
+    p[i] = t + r[i];
+  }
+  if (leader) st->res = res;
+}
+
+}  // namespace mk
+
+struct mk_bicgstab {
+  int max_iter = 1000;   // solvers.c:83
+  double tol = 1e-6;     // solvers.c:84
+  int print_level = 0, logging = 0, check_every = 16;
+  int64_t n = 0;
+  double *r0 = nullptr, *r = nullptr, *p = nullptr, *q = nullptr, *s = nullptr;
+  double *slab1 = nullptr, *slab2 = nullptr;
+  mk::BicgState *state = nullptr;
+  double *norms = nullptr;
+  int norms_cap = 0;
+  long long iterations = 0;
+  double rel_res_norm = 0.0;
+  int converged = 0, breakdown = 0;
+};
+
+using namespace mk;
+
+static void bicg_release(mk_bicgstab *S) {
+  dev_free(S->r0); dev_free(S->r); dev_free(S->p); dev_free(S->q); dev_free(S->s);
+  dev_free(S->slab1); dev_free(S->slab2); dev_free(S->state); dev_free(S->norms);
+  S->r0 = S->r = S->p = S->q = S->s = S->slab1 = S->slab2 = S->norms = nullptr;
+  S->state = nullptr;
+  S->n = 0;
+}
+
+extern "C" {
+
+int mk_bicgstab_create(mk_bicgstab **solver) {
+  MK_REQUIRE_INIT();
+  if (!solver) return fail(MK_ERR_INVALID, "mk_bicgstab_create: null argument");
+  *solver = new mk_bicgstab();
+  return MK_OK;
+}
+
+#define MK_BICG_SETTER(name, field, type, cond)                                       \
+  int name(mk_bicgstab *solver, type v) {                                              \
+    if (!solver) return fail(MK_ERR_INVALID, #name ": null solver");                   \
+    if (!(cond)) return fail(MK_ERR_INVALID, #name ": value out of range");            \
+    solver->field = v;                                                                 \
+    return MK_OK;                                                                      \
+  }
+MK_BICG_SETTER(mk_bicgstab_set_max_iter, max_iter, int, v >= 0)
+MK_BICG_SETTER(mk_bicgstab_set_tol, tol, double, v >= 0.0)
+MK_BICG_SETTER(mk_bicgstab_set_print_level, print_level, int, v >= 0)
+MK_BICG_SETTER(mk_bicgstab_set_logging, logging, int, v >= 0)
+MK_BICG_SETTER(mk_bicgstab_set_check_every, check_every, int, v >= 1)
+#undef MK_BICG_SETTER
+
+int mk_bicgstab_setup(mk_bicgstab *S, const mk_matrix *A, const mk_vector *b, const mk_vector *x) {
+  MK_REQUIRE_INIT();
+  if (!S || !A || !b || !x) return fail(MK_ERR_INVALID, "mk_bicgstab_setup: null argument");
+  if (A->nrows != A->ncols) return fail(MK_ERR_INVALID, "mk_bicgstab_setup: matrix is %lld x %lld, must be square", (long long)A->nrows, (long long)A->ncols);
+  if (b->n != A->nrows || x->n != A->nrows) return fail(MK_ERR_INVALID, "mk_bicgstab_setup: vector length does not match the matrix");
+  bicg_release(S);
+  S->n = A->nrows;
+  MK_TRY(dev_alloc(&S->r0, (size_t)S->n));
+  MK_TRY(dev_alloc(&S->r, (size_t)S->n));
+  MK_TRY(dev_alloc(&S->p, (size_t)S->n));
+  MK_TRY(dev_alloc(&S->q, (size_t)S->n));
+  MK_TRY(dev_alloc(&S->s, (size_t)S->n));
+  MK_TRY(dev_alloc(&S->slab1, (size_t)2 * kSlabStride));
+  MK_TRY(dev_alloc(&S->slab2, (size_t)2 * kSlabStride));
+  MK_TRY(dev_alloc(&S->state, 1));
+  if (S->logging > 0 || S->print_level > 0) {
+    S->norms_cap = S->max_iter + 1;
+    MK_TRY(dev_alloc(&S->norms, (size_t)S->norms_cap));
+  }
+  MK_TRY(analyse_matrix(const_cast<mk_matrix *>(A)));
+  MK_HIP(hipStreamSynchronize(ctx().stream));
+  return MK_OK;
+}
+
+int mk_bicgstab_solve(mk_bicgstab *S, const mk_matrix *A, const mk_vector *b, mk_vector *x) {
+  MK_REQUIRE_INIT();
+  if (!S || !A || !b || !x) return fail(MK_ERR_INVALID, "mk_bicgstab_solve: null argument");
+  if (S->n != A->nrows || !S->state) return fail(MK_ERR_INVALID, "mk_bicgstab_solve: call mk_bicgstab_setup with this matrix first");
+  if (b->n != S->n || x->n != S->n) return fail(MK_ERR_INVALID, "mk_bicgstab_solve: vector length does not match the matrix");
+  if (S->norms && S->norms_cap < S->max_iter + 1) return fail(MK_ERR_INVALID, "mk_bicgstab_solve: max_iter was raised after setup");
+  Context &c = ctx();
+  const int64_t n = S->n;
+  S->iterations = 0; S->rel_res_norm = 0.0; S->converged = 0; S->breakdown = 0;
+  if (n == 0) return MK_OK;
+  const int vb = vec_blocks(n);
+  const dim3 grid(vb), block(kVecThreads);
+  BicgState *hst = static_cast<BicgState *>(c.pinned);
+
+  hipLaunchKernelGGL(copy_kernel, grid, dim3(256), 0, c.stream, S->r0, b->d, n);
+  MK_TRY(launch_spmv(A, -1.0, x->d, 1.0, S->r0));
+  hipLaunchKernelGGL(bicg_init_vectors_kernel, grid, block, 0, c.stream, n, b->d, S->r0, S->r, S->p, S->slab1);
+  hipLaunchKernelGGL(bicg_init_scalars_kernel, dim3(1), block, 0, c.stream, S->slab1, vb, S->tol, S->state, S->norms);
+
+  bool stop = false;
+  for (int it = 0; it < S->max_iter && !stop; it++) {
+    int *done = &S->state->done, *skip = &S->state->skip_true;
+    MK_TRY(launch_spmv(A, 1.0, S->p, 0.0, S->q, done));
+    hipLaunchKernelGGL(dot2_kernel, grid, block, 0, c.stream, n, S->r0, S->q, nullptr, nullptr, S->slab1, done);
+    hipLaunchKernelGGL(bicg_step1_kernel, grid, block, 0, c.stream, n, S->p, S->q, x->d, S->r, S->slab1, vb, S->state);
+    MK_TRY(launch_spmv(A, 1.0, S->r, 0.0, S->s, done));
+    hipLaunchKernelGGL(dot2_kernel, grid, block, 0, c.stream, n, S->r, S->s, S->s, S->s, S->slab2, done);
+    hipLaunchKernelGGL(bicg_step2_kernel, grid, block, 0, c.stream, n, S->s, x->d, S->r, S->slab2, vb, S->slab1, S->state);
+    hipLaunchKernelGGL(bicg_norm_kernel, dim3(1), block, 0, c.stream, S->slab1, vb, S->state, S->norms);
+    // only when the recursive residual passed: r = b - A x (skip_true is 1 otherwise, and after a stop)
+    hipLaunchKernelGGL(copy_unless_kernel, grid, dim3(256), 0, c.stream, S->r, b->d, n, skip);
+    MK_TRY(launch_spmv(A, -1.0, x->d, 1.0, S->r, skip));
+    hipLaunchKernelGGL(dot2_kernel, grid, block, 0, c.stream, n, S->r0, S->r, S->r, S->r, S->slab2, done);
+    hipLaunchKernelGGL(bicg_step3_kernel, grid, block, 0, c.stream, n, S->r, S->q, S->p, S->slab2, vb, S->state);
+    if ((it + 1) % S->check_every == 0) {
+      MK_HIP(hipMemcpyAsync(&hst[0], S->state, sizeof(BicgState), hipMemcpyDeviceToHost, c.stream));
+      MK_HIP(hipStreamSynchronize(c.stream));
+      if (hst[0].done != 0) stop = true;
+    }
+  }
+  MK_HIP(hipGetLastError());
+  MK_HIP(hipMemcpyAsync(&hst[0], S->state, sizeof(BicgState), hipMemcpyDeviceToHost, c.stream));
+  MK_HIP(hipStreamSynchronize(c.stream));
+  S->iterations = hst[0].iter;
+  S->converged = hst[0].converged;
+  S->breakdown = hst[0].breakdown;
+  S->rel_res_norm = hst[0].b_norm > 0.0 ? hst[0].r_norm / hst[0].b_norm : hst[0].r_norm;
+  if (S->print_level > 1)
+    printf("BiCGSTAB: %lld iterations, relative residual %e%s\n", S->iterations, S->rel_res_norm, S->converged ? "" : " (not converged)");
+  return MK_OK;
+}
+
+int mk_bicgstab_get_num_iterations(const mk_bicgstab *S, long long *iterations) {
+  if (!S || !iterations) return fail(MK_ERR_INVALID, "mk_bicgstab_get_num_iterations: null argument");
+  *iterations = S->iterations;
+  return MK_OK;
+}
+
+int mk_bicgstab_get_final_relative_residual_norm(const mk_bicgstab *S, double *norm) {
+  if (!S || !norm) return fail(MK_ERR_INVALID, "mk_bicgstab_get_final_relative_residual_norm: null argument");
+  *norm = S->rel_res_norm;
+  return MK_OK;
+}
+
+int mk_bicgstab_get_converged(const mk_bicgstab *S, int *converged, int *breakdown) {
+  if (!S) return fail(MK_ERR_INVALID, "mk_bicgstab_get_converged: null solver");
+  if (converged) *converged = S->converged;
+  if (breakdown) *breakdown = S->breakdown;
+  return MK_OK;
+}
+
+int mk_bicgstab_get_residual_history(const mk_bicgstab *S, double *norms, int capacity) {
+  MK_REQUIRE_INIT();
+  if (!S || !norms || capacity < 0) return fail(MK_ERR_INVALID, "mk_bicgstab_get_residual_history: bad argument");
+  if (!S->norms) return fail(MK_ERR_INVALID, "mk_bicgstab_get_residual_history: logging was off at setup");
+  int count = (int)std::min<long long>(S->iterations + 1, capacity);
+  if (S->breakdown == 1) count = (int)std::min<long long>(S->iterations, capacity);   // no norm for the aborted step
+  if (count > 0) {
+    MK_HIP(hipMemcpyAsync(norms, S->norms, sizeof(double) * count, hipMemcpyDeviceToHost, ctx().stream));
+    MK_HIP(hipStreamSynchronize(ctx().stream));
+  }
+  return count;
+}
+
+int mk_bicgstab_destroy(mk_bicgstab *S) {
+  if (!S) return MK_OK;
+  if (ctx().ready) (void)hipStreamSynchronize(ctx().stream);
+  bicg_release(S);
+  delete S;
+  return MK_OK;
+}
+
+}  // extern "C"

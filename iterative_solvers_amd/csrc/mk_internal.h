@@ -166,7 +166,8 @@ int ensure_dinv(mk_matrix *A);
 
 // launchers shared between translation units (all enqueue on ctx().stream)
 // y = alpha*A*x + beta*y
-int launch_spmv(const mk_matrix *A, double alpha, const double *x, double beta, double *y);
+// `skip` (may be null): device flag, nonzero -> the kernel returns at once
+int launch_spmv(const mk_matrix *A, double alpha, const double *x, double beta, double *y, const int *skip = nullptr);
 // y = A*x, partial sums of <y,x>,<x,x> into slab (components 0,1); returns blocks used.
 // `done` (may be null) is a device flag: nonzero -> kernel returns at once.
 int launch_spmv_dot(const mk_matrix *A, const double *x, double *y, double *slab, const int *done, int *nblocks);

@@ -1466,14 +1466,14 @@ static int launch_split(const mk_matrix *A, double alpha, const double *x, doubl
   return MK_OK;
 }
 
-int launch_spmv(const mk_matrix *A, double alpha, const double *x, double beta, double *y) {
+int launch_spmv(const mk_matrix *A, double alpha, const double *x, double beta, double *y, const int *skip) {
   MK_TRY(analyse_matrix(const_cast<mk_matrix *>(A)));
   if (A->nrows == 0) return MK_OK;
-  if (A->kernel == MK_SPMV_SWEEP) return launch_sweep<0>(A, alpha, x, beta, y, nullptr, nullptr, nullptr);
-  if (A->kernel == MK_SPMV_PATTERN) return launch_pattern<0>(A, alpha, x, beta, y, nullptr, nullptr, nullptr);
-  if (A->kernel == MK_SPMV_STREAM) return launch_stream<0>(A, alpha, x, beta, y, nullptr, nullptr, nullptr);
-  if (A->kernel == MK_SPMV_SPLIT) return launch_split<0>(A, alpha, x, beta, y, nullptr, nullptr, nullptr);
-  return launch_vector<0>(A, alpha, x, beta, y, nullptr, nullptr, nullptr);
+  if (A->kernel == MK_SPMV_SWEEP) return launch_sweep<0>(A, alpha, x, beta, y, nullptr, skip, nullptr);
+  if (A->kernel == MK_SPMV_PATTERN) return launch_pattern<0>(A, alpha, x, beta, y, nullptr, skip, nullptr);
+  if (A->kernel == MK_SPMV_STREAM) return launch_stream<0>(A, alpha, x, beta, y, nullptr, skip, nullptr);
+  if (A->kernel == MK_SPMV_SPLIT) return launch_split<0>(A, alpha, x, beta, y, nullptr, skip, nullptr);
+  return launch_vector<0>(A, alpha, x, beta, y, nullptr, skip, nullptr);
 }
 
 // one Jacobi sweep through the stream kernel; returns MK_ERR_UNSUPPORTED when the matrix does not

@@ -450,3 +450,71 @@ int64_t orc_banded_csr(int64_t n, int hb, int *rowptr, int *col, double *val) {
   if (rowptr) rowptr[n] = (int)k;
   return k;
 }
+
+/* ---- BiCGSTAB (solver id 6, solvers.c:517-564: Tol, MaxIter, identity preconditioner) -------
+ * Restatement of the published hypre_BiCGSTABSolve loop (HYPRE is absent from /root/reference):
+ *   r0 = b - A x; r = p = r0; res = <r0,r0>; eps = tol * ||b|| (||r0|| when b = 0)
+ *   loop: v = p; q = A v; temp = <r0,q>; alpha = res/temp; x += alpha v; r -= alpha q;
+ *         v = r; s = A v; gamma = <r,s>/<s,s> (0/0 := 0); x += gamma v; r -= gamma s;
+ *         ||r|| <= eps ? recompute r = b - A x, and stop if still <= eps;
+ *         beta = (<r0,r>/res) * (alpha/gamma); res = <r0,r>; p = beta (p - gamma q) + r.
+ *   breakdown when |temp|, |res| or |gamma| < 1e-128.  rel_res_norm = ||r||/||b||.
+ * PARITY UNPINNED: nothing in /root/reference fixes these results. */
+void orc_bicgstab(uint32_t n, const int *rowptr, const int *col, const double *val, const double *b,
+                  double *x, double tol, int maxit, int use_omp, orc_solve_info *info, double *norms) {
+  const double epsmac = 1.e-128;
+  double *r0 = (double *)malloc(sizeof(double) * n), *r = (double *)malloc(sizeof(double) * n);
+  double *p = (double *)malloc(sizeof(double) * n), *q = (double *)malloc(sizeof(double) * n);
+  double *sv = (double *)malloc(sizeof(double) * n);
+  info->iterations = 0; info->converged = 0; info->breakdown = 0; info->rel_res_norm = 0.0;
+  memcpy(r0, b, sizeof(double) * n);
+  spmv(n, rowptr, col, val, -1.0, x, 1.0, r0, use_omp);
+  memcpy(r, r0, sizeof(double) * n);
+  memcpy(p, r0, sizeof(double) * n);
+  const double b_norm = sqrt(v_dot(n, b, b, use_omp));
+  double res = v_dot(n, r0, r0, use_omp);
+  double r_norm = sqrt(res);
+  if (norms) norms[0] = r_norm;
+  const double den_norm = b_norm > 0.0 ? b_norm : r_norm;
+  const double eps = tol * den_norm;
+  long long iter = 0;
+  if (r_norm == 0.0) goto done;
+  while (iter < maxit) {
+    iter++;
+    spmv(n, rowptr, col, val, 1.0, p, 0.0, q, use_omp);
+    const double temp = v_dot(n, r0, q, use_omp);
+    if (!(fabs(temp) >= epsmac)) { info->breakdown = 1; break; }
+    const double alpha = res / temp;
+    v_axpy(n, alpha, p, x, use_omp);
+    v_axpy(n, -alpha, q, r, use_omp);
+    spmv(n, rowptr, col, val, 1.0, r, 0.0, sv, use_omp);
+    const double gnum = v_dot(n, r, sv, use_omp), gden = v_dot(n, sv, sv, use_omp);
+    const double gamma = (gnum == 0.0 && gden == 0.0) ? 0.0 : gnum / gden;
+    v_axpy(n, gamma, r, x, use_omp);
+    v_axpy(n, -gamma, sv, r, use_omp);
+    r_norm = sqrt(v_dot(n, r, r, use_omp));
+    if (norms) norms[iter] = r_norm;
+    if (r_norm <= eps) {
+      memcpy(r, b, sizeof(double) * n);
+      spmv(n, rowptr, col, val, -1.0, x, 1.0, r, use_omp);
+      r_norm = sqrt(v_dot(n, r, r, use_omp));
+      if (r_norm <= eps) { info->converged = 1; break; }
+    }
+    if (!(fabs(res) >= epsmac)) { info->breakdown = 2; break; }
+    double beta = 1.0 / res;
+    res = v_dot(n, r0, r, use_omp);
+    beta *= res;
+    beta *= alpha;
+    if (!(fabs(gamma) >= epsmac)) { info->breakdown = 3; break; }
+    beta /= gamma;
+    for (uint32_t i = 0; i < n; i++) {
+      double t = p[i] + (-gamma) * q[i];
+      t = beta * t;
+      p[i] = t + r[i];
+    }
+  }
+done:
+  info->iterations = iter;
+  info->rel_res_norm = b_norm > 0.0 ? r_norm / b_norm : r_norm;
+  free(r0); free(r); free(p); free(q); free(sv);
+}

@@ -76,6 +76,11 @@ void orc_jacobi(uint32_t n, const int *rowptr, const int *col, const double *val
                 const double *b, double *x, double tol, int maxit, int check_every,
                 int use_omp, orc_solve_info *info);
 
+/* BiCGSTAB as solvers.c:517-564 drives it (solver id 6: tol, maxit, identity preconditioner); breakdown:
+ * 1 <r0,q> ~ 0, 2 res ~ 0, 3 gamma ~ 0.  norms may be NULL or hold maxit+1 doubles (absolute ||r||). */
+void orc_bicgstab(uint32_t n, const int *rowptr, const int *col, const double *val, const double *b,
+                  double *x, double tol, int maxit, int use_omp, orc_solve_info *info, double *norms);
+
 /* ---- synthetic matrices (bench.py / tests; same definitions as the device generators) */
 uint64_t orc_splitmix64(uint64_t x);
 /* R-MAT edge i of a 2^scale graph: row/col bits drawn from counter-based splitmix64 */

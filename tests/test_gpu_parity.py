@@ -548,6 +548,76 @@ def test_pcg_tol_zero_runs_exactly_maxit():
     assert S.solve(A, b, x)["iterations"] == 20
 
 
+# ------------------------------------------------------------------ BiCGSTAB (solver id 6)
+def _convection_diffusion(kind, dims, c=0.4):
+    rp, ci, v = oracle.stencil_csr(kind, *dims)
+    n = rp.size - 1
+    rows = np.repeat(np.arange(n), np.diff(rp))
+    v = v.copy()
+    v[ci == rows + 1] += c          # upwind-ish first-order term: nonsymmetric
+    v[ci == rows - 1] -= c
+    return rp, ci, v, n
+
+
+@pytest.mark.parametrize("kind,dims,kernel", [(5, (64, 48, 1), None), (7, (20, 16, 12), None), (7, (32, 16, 12), "sweep"),
+                                              (7, (20, 16, 12), "vector")])
+def test_bicgstab_matches_oracle(kind, dims, kernel):
+    rp, ci, v, n = _convection_diffusion(kind, dims)
+    rng = np.random.default_rng(11)
+    bh = rng.normal(size=n)
+    tol = 1e-9
+    o = oracle.bicgstab(rp, ci, v, bh, tol=tol, maxit=500, want_norms=True)
+    A = mk.Matrix.from_csr(n, n, rp, ci, v)
+    if kernel == "sweep":
+        A.set_spmv_kernel(mk.SPMV_SWEEP)
+    elif kernel == "vector":
+        A.set_spmv_kernel(mk.SPMV_VECTOR)
+    for check_every in (1, 16):
+        b, x = mk.Vector(n, values=bh), mk.Vector(n, fill=0.0)
+        S = mk.BiCGSTAB(max_iter=500, tol=tol, logging=1, check_every=check_every)
+        S.setup(A, b, x)
+        res = S.solve(A, b, x)
+        assert res["converged"] == 1 == o["converged"]
+        # irregular convergence magnifies the other summation order of the dots: 5 % of the count, at least 3
+        assert abs(res["iterations"] - o["iterations"]) <= max(3, 0.05 * o["iterations"]), (res, o["iterations"])
+        xs = x.get()
+        true_rel = np.linalg.norm(bh - oracle.csr_spmv(rp, ci, v, xs)) / np.linalg.norm(bh)
+        assert true_rel <= tol * 1.0001 and abs(res["rel_res_norm"] - true_rel) <= 1e-3 * tol
+        assert np.linalg.norm(xs - o["x"]) <= 1e-6 * np.linalg.norm(o["x"])
+        hist = S.residual_history(1000)
+        assert hist.size == res["iterations"] + 1
+        m = min(hist.size, o["norms"].size, 12)      # BiCGSTAB histories drift apart sooner than CG's
+        assert np.allclose(hist[:m], o["norms"][:m], rtol=1e-6)
+
+
+def test_bicgstab_maxit_restart_and_zero_residual():
+    rp, ci, v, n = _convection_diffusion(5, (40, 40, 1))
+    A = mk.Matrix.from_csr(n, n, rp, ci, v)
+    b, x = mk.Vector(n, fill=1.0), mk.Vector(n, fill=0.0)
+    S = mk.BiCGSTAB(max_iter=4, tol=1e-14)
+    S.setup(A, b, x)
+    res = S.solve(A, b, x)
+    o = oracle.bicgstab(rp, ci, v, np.ones(n), tol=1e-14, maxit=4)
+    assert res["iterations"] == 4 and res["converged"] == 0
+    assert np.isclose(res["rel_res_norm"], o["rel_res_norm"], rtol=1e-8)
+    assert np.allclose(x.get(), o["x"], rtol=1e-9, atol=1e-13)
+    res2 = S.solve(A, b, x)          # niter > 1 in the reference re-solves from the previous x (solvers.c:541-542)
+    o2 = oracle.bicgstab(rp, ci, v, np.ones(n), x0=o["x"], tol=1e-14, maxit=4)
+    assert np.isclose(res2["rel_res_norm"], o2["rel_res_norm"], rtol=1e-7)
+    # the exact solution as start: zero residual, zero iterations
+    xs = np.linalg.solve(_dense(rp, ci, v, n), np.ones(n)) if n <= 2000 else None
+    b0, x0 = mk.Vector(n, fill=0.0), mk.Vector(n, fill=0.0)
+    r0 = S.solve(A, b0, x0)
+    assert r0["iterations"] == 0 and np.all(x0.get() == 0.0)
+
+
+def _dense(rp, ci, v, n):
+    M = np.zeros((n, n))
+    rows = np.repeat(np.arange(n), np.diff(rp))
+    np.add.at(M, (rows, ci), v)
+    return M
+
+
 @pytest.mark.parametrize("check_every", [1, 5])
 def test_jacobi_banded_matches_oracle(check_every):
     # config 5 shape scaled down

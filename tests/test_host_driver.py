@@ -188,6 +188,23 @@ def test_driver_pcg_output_lines(tmp_path, solver, precond):
 
 
 @pytest.mark.gpu
+def test_driver_bicgstab_output_lines(tmp_path):
+    # solver id 6 (solvers.c:517-564) on the same synthetic .mtx path
+    mtx = tmp_path / "poisson.mtx"
+    rp, ci, v = _write_poisson(mtx, 48, 40, shuffle_seed=3)
+    out = subprocess.run([os.path.join(HOST, "solver"), "-solver", "6", "-mtx", str(mtx), "-tol", "1e-8",
+                          "-maxit", "500", "-log", "0"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert re.search(r"^ParCSRBiCGSTABC Solve time = [0-9.]+ seconds$", out.stdout, re.M)     # the reference's spelling (:550)
+    it = int(re.search(r"^Iterations = (\d+)$", out.stdout, re.M).group(1))
+    nrm = float(re.search(r"^Final Relative Residual Norm = ([0-9.e+-]+)$", out.stdout, re.M).group(1))
+    o = oracle.bicgstab(rp, ci, v, np.ones(rp.size - 1), tol=1e-8, maxit=500)
+    # BiCGSTAB's irregular convergence magnifies the different summation order of the dot products:
+    # the bar for the count is 5 % (at least 3 iterations), the residual itself must meet the tolerance
+    assert abs(it - o["iterations"]) <= max(3, 0.05 * o["iterations"]) and nrm <= 1e-8
+
+
+@pytest.mark.gpu
 def test_driver_binary_cache(tmp_path):
     mtx = tmp_path / "poisson.mtx"
     _write_poisson(mtx, 40, 40, shuffle_seed=2)
