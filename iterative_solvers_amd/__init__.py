@@ -65,7 +65,7 @@ EXPORTS = [
     "mk_jacobi_get_final_relative_residual_norm", "mk_jacobi_get_converged", "mk_jacobi_destroy",
     "mk_partition_rows",
     "mk_comm_get_unique_id", "mk_comm_create", "mk_comm_create_local", "mk_comm_self_test", "mk_comm_destroy",
-    "mk_dist_matrix_create", "mk_dist_matrix_destroy", "mk_dist_matrix_get_info",
+    "mk_dist_matrix_create", "mk_dist_matrix_destroy", "mk_dist_matrix_get_info", "mk_dist_matrix_set_spmv_kernel",
     "mk_dist_vector_create", "mk_dist_spmv", "mk_dist_pcg_solve", "mk_dist_jacobi_solve",
 ]
 

@@ -25,6 +25,8 @@
 
 #include <algorithm>
 
+#include <cfloat>
+
 #include "krylov_kernels.h"
 
 struct mk_dist_matrix;
@@ -191,7 +193,8 @@ __global__ void pack_kernel(int n, const int *__restrict__ idx, const double *__
 // y[rows[i]] += alpha * sum_k val[k] * xghost[col[k]]  over the offd block; with DOT the
 // per-block partial of sum_i (contribution_i * xlocal[rows[i]]) goes to slab component 0
 // (component 1 gets 0) so that <A p, p> can be completed after the diag pass.
-template <int G, bool DOT, bool SET>
+// COMPACT: y is a vector over the compressed list of rows (t[i]) instead of over the local rows (y[rows[i]])
+template <int G, bool DOT, bool SET, bool COMPACT = false>
 __global__ __launch_bounds__(256) void offd_spmv_kernel(int nrows, const int *__restrict__ rowptr, const int *__restrict__ col,
                                                         const double *__restrict__ val, const int *__restrict__ rows,
                                                         const double *__restrict__ xghost, const double *__restrict__ xlocal,
@@ -210,7 +213,9 @@ __global__ __launch_bounds__(256) void offd_spmv_kernel(int nrows, const int *__
     if (g == 0 && i < nrows) {
       const int r = rows[i];
       const double add = alpha * sum;
-      if (SET) y[r] = add; else y[r] += add;
+      if (COMPACT) y[i] = add;
+      else if (SET) y[r] = add;
+      else y[r] += add;
       if (DOT) acc += add * xlocal[r];
     }
   }
@@ -435,10 +440,39 @@ static int launch_offd(const mk_dist_matrix *D, const double *xext, double *y, d
   return MK_OK;
 }
 
+// t[i] = (offd x_ghost)[i] over the rows that touch ghosts, partial of <t, x_local> (fused row-block CG step)
+static int launch_offd_compact(const mk_dist_matrix *D, const double *xext, double *t, double *slab, const int *done, int *nblocks) {
+  Context &c = ctx();
+  const int G = D->offd_lanes;
+  const int rows_per_block = 256 / G;
+  int blocks = std::max(1, std::min((D->n_offd_rows + rows_per_block - 1) / rows_per_block, 1024));
+  if (nblocks) *nblocks = blocks;
+#define MK_OFFD(GG) case GG: hipLaunchKernelGGL((offd_spmv_kernel<GG, true, true, true>), dim3(blocks), dim3(256), 0, c.stream, D->n_offd_rows, \
+    D->offd.rowptr, D->offd.col, D->offd.val, D->offd_rows, xext + D->n_local, xext, t, 1.0, slab, done); break;
+  switch (G) { MK_OFFD(1) MK_OFFD(2) MK_OFFD(4) MK_OFFD(8) MK_OFFD(16) MK_OFFD(32) MK_OFFD(64) default: return fail(MK_ERR_INVALID, "offd lanes"); }
+#undef MK_OFFD
+  MK_HIP(hipGetLastError());
+  return MK_OK;
+}
+
+// r[rows[i]] -= alpha t[i] with alpha = gamma / <A p, p> (all-reduced pair in buf); the sweep that follows does
+// the diag part of the same update and owns the breakdown bookkeeping, this kernel only mirrors its tests
+static __global__ void offd_resid_kernel(int nrows, const int *__restrict__ rows, const double *__restrict__ t, double *__restrict__ r,
+                                         const double *__restrict__ buf, const PcgState *st) {
+  if (st->done != 0) return;
+  const double sdotp = buf[0];
+  if (sdotp == 0.0) return;
+  const double alpha = st->gamma / sdotp;
+  if (!(alpha > DBL_MIN)) return;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nrows; i += gridDim.x * blockDim.x) r[rows[i]] -= alpha * t[i];
+}
+
 struct DistWork {
   double *r = nullptr, *p = nullptr, *s = nullptr, *slab1 = nullptr, *slab2 = nullptr, *buf = nullptr, *norms = nullptr;
+  double *t = nullptr;   // fused step: off-rank part of A p over the rows that touch ghosts
   PcgState *state = nullptr;
   void release() {
+    dev_free(t);
     dev_free(r); dev_free(p); dev_free(s); dev_free(slab1); dev_free(slab2); dev_free(buf); dev_free(state); dev_free(norms);
   }
 };
@@ -624,6 +658,11 @@ int mk_dist_matrix_get_info(const mk_dist_matrix *D, int64_t *n_local, int64_t *
   return MK_OK;
 }
 
+int mk_dist_matrix_set_spmv_kernel(mk_dist_matrix *D, int kernel, int lanes_per_row) {
+  if (!D) return fail(MK_ERR_INVALID, "mk_dist_matrix_set_spmv_kernel: null matrix");
+  return mk_matrix_set_spmv_kernel(&D->diag, kernel, lanes_per_row);
+}
+
 int mk_dist_vector_create(const mk_dist_matrix *D, mk_vector **v) {
   MK_REQUIRE_INIT();
   if (!D || !v) return fail(MK_ERR_INVALID, "mk_dist_vector_create: null argument");
@@ -690,7 +729,8 @@ int mk_dist_pcg_solve(int R, mk_pcg **solvers, mk_dist_matrix **A, mk_vector **b
   const bool want_norms = S0->logging > 0 || S0->print_level > 0;
   std::vector<DistWork> W(R);
   std::vector<double *> pv(R), xv(R), bufs(R);
-  std::vector<int> vb(R), nb1(R), nb2(R);
+  std::vector<int> vb(R), nb1(R), nb2(R), fusedv(R, 0);
+  static const int no_fused = getenv("MK_NO_FUSED_CG") ? atoi(getenv("MK_NO_FUSED_CG")) : 0;
   int rc = MK_OK;
   auto cleanup = [&]() { (void)hipDeviceSynchronize(); for (auto &w : W) w.release(); };
 #define MK_D(expr) do { rc = (expr); if (rc != MK_OK) { cleanup(); return rc; } } while (0)
@@ -710,6 +750,10 @@ int mk_dist_pcg_solve(int R, mk_pcg **solvers, mk_dist_matrix **A, mk_vector **b
     if (S0->precond == MK_PRECOND_JACOBI) MK_D(ensure_dinv(&D->diag));   // the diagonal lives in the diag block
     pv[r] = W[r].p; xv[r] = x[r]->d; bufs[r] = W[r].buf;
     vb[r] = vec_blocks(D->n_local);
+    // diag blocks served by the sweep kernel take the fused step (A p recomputed instead of stored; 76 B per row
+    // and iteration instead of 90).  Decided per rank: both variants all-reduce the same 2 + 3 values.
+    fusedv[r] = (D->diag.kernel == MK_SPMV_SWEEP) && !no_fused && D->n_local > 0;
+    if (fusedv[r]) MK_D(dev_alloc(&W[r].t, (size_t)std::max(D->n_offd_rows, 1)));
     solvers[r]->iterations = 0; solvers[r]->rel_res_norm = 0.0; solvers[r]->converged = 0; solvers[r]->breakdown = 0;
   }
   PcgState *hst = static_cast<PcgState *>(c.pinned);
@@ -741,22 +785,32 @@ int mk_dist_pcg_solve(int R, mk_pcg **solvers, mk_dist_matrix **A, mk_vector **b
   bool stop = zero_rhs;
   for (int it = 0; it < S0->max_iter && !stop; it++) {
     MK_D(halo_exchange(R, A, pv.data(), rccl));                                  // on the communication stream over RCCL
-    for (int r = 0; r < R; r++)                                                   // K1a: diag block, overlaps the halo
-      MK_D(launch_spmv_dot(&A[r]->diag, W[r].p, W[r].s, W[r].slab1, &W[r].state->done, &nb1[r]));
+    for (int r = 0; r < R; r++) {                                                 // K1a: diag block, overlaps the halo
+      if (fusedv[r]) MK_D(launch_sweep_cg_dots(&A[r]->diag, W[r].p, W[r].slab1, W[r].state, nullptr, 0, &nb1[r]));
+      else MK_D(launch_spmv_dot(&A[r]->diag, W[r].p, W[r].s, W[r].slab1, &W[r].state->done, &nb1[r]));
+    }
     for (int r = 0; r < R; r++) {                                                 // K1b: offd block once the ghosts are in
       MK_D(halo_wait(A[r], rccl));
-      MK_D(launch_offd<true>(A[r], W[r].p, W[r].s, 1.0, W[r].slab1 + nb1[r], &W[r].state->done, &nb2[r]));
+      if (fusedv[r]) MK_D(launch_offd_compact(A[r], W[r].p, W[r].t, W[r].slab1 + nb1[r], &W[r].state->done, &nb2[r]));
+      else MK_D(launch_offd<true>(A[r], W[r].p, W[r].s, 1.0, W[r].slab1 + nb1[r], &W[r].state->done, &nb2[r]));
       hipLaunchKernelGGL((finalize_slab_kernel<2>), dim3(1), dim3(kVecThreads), 0, c.stream, W[r].slab1, nb1[r] + nb2[r], W[r].buf);
     }
     MK_D(all_reduce(R, A, bufs.data(), 2));                                       // <s,p>, <p,p>
     for (int r = 0; r < R; r++) {
       const int64_t nl = A[r]->n_local;
       double *buf3 = W[r].buf + 4;
-      if (S0->precond == MK_PRECOND_JACOBI)
+      int nbk2 = vb[r];
+      if (fusedv[r]) {
+        if (A[r]->n_offd_rows > 0)
+          hipLaunchKernelGGL(offd_resid_kernel, dim3(grid1(A[r]->n_offd_rows, 1024)), dim3(256), 0, c.stream, A[r]->n_offd_rows,
+                             A[r]->offd_rows, W[r].t, W[r].r, W[r].buf, W[r].state);
+        MK_D(launch_sweep_cg_resid_x(&A[r]->diag, W[r].p, W[r].r, x[r]->d, S0->precond == MK_PRECOND_JACOBI ? A[r]->diag.dinv : nullptr,
+                                     W[r].buf, 1, 1, W[r].slab2, W[r].state, &nbk2));
+      } else if (S0->precond == MK_PRECOND_JACOBI)
         hipLaunchKernelGGL((pcg_update_xr_kernel<true>), dim3(vb[r]), dim3(kVecThreads), 0, c.stream, nl, W[r].p, W[r].s, A[r]->diag.dinv, x[r]->d, W[r].r, W[r].buf, 1, 1, W[r].slab2, W[r].state);
       else
         hipLaunchKernelGGL((pcg_update_xr_kernel<false>), dim3(vb[r]), dim3(kVecThreads), 0, c.stream, nl, W[r].p, W[r].s, (const double *)nullptr, x[r]->d, W[r].r, W[r].buf, 1, 1, W[r].slab2, W[r].state);
-      hipLaunchKernelGGL((finalize_slab_kernel<3>), dim3(1), dim3(kVecThreads), 0, c.stream, W[r].slab2, vb[r], buf3);
+      hipLaunchKernelGGL((finalize_slab_kernel<3>), dim3(1), dim3(kVecThreads), 0, c.stream, W[r].slab2, nbk2, buf3);
       bufs[r] = buf3;
     }
     MK_D(all_reduce(R, A, bufs.data(), 3));                                       // <r,z>, <r,r>, <x,x>

@@ -142,7 +142,7 @@ struct mk_matrix {
   unsigned *pmask = nullptr;       // device, npat: which entries of the base pattern each pattern keeps
   mk::SweepEntry *etab = nullptr;  // device, 32 entries
   bool sweep_auto = false;         // enough parallelism for the sweep kernel to be the default
-  mutable int sweep_bpc[5] = {0, 0, 0, 0, 0};
+  mutable int sweep_bpc[6] = {0, 0, 0, 0, 0, 0};
   int npat = 0, pml = 0;
   int max_off = 0;                 // largest |column - row| over all patterns
   // split kernel: chunk c covers entries [c*kSplitChunk, (c+1)*kSplitChunk); chunk_row[c] = first row starting in it
@@ -184,6 +184,11 @@ int launch_sweep_cg_dots(const mk_matrix *A, const double *p, double *slab_out, 
                          int nblocks_xx, int *nblocks);
 int launch_sweep_cg_resid(const mk_matrix *A, const double *p, double *r, const double *dinv, const double *slab_in,
                           int nblocks_in, double *slab_out, PcgState *st, int *nblocks);
+
+// row-block solver: as resid, plus x += alpha p and the partial of <x,x> (component 2); alpha from slab_in with
+// the given stride between its two components (1 for an all-reduced pair)
+int launch_sweep_cg_resid_x(const mk_matrix *A, const double *p, double *r, double *x, const double *dinv, const double *slab_in,
+                            int nblocks_in, int stride_in, double *slab_out, PcgState *st, int *nblocks);
 
 int exclusive_scan_u32(const uint32_t *in, uint32_t *out, size_t n, uint32_t *total_out_dev);
 

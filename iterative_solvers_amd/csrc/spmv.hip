@@ -1016,11 +1016,12 @@ __global__ __launch_bounds__(kThreads) void spmv_sweep_kernel(
     const SweepArgs S, const SweepEntry *__restrict__ etab, int64_t nrows, int64_t ncols, const unsigned short *__restrict__ pat,
     const unsigned *__restrict__ pmask, int npat, const double *__restrict__ x, double *__restrict__ y, double alpha, double beta, double *__restrict__ slab,
     const int *__restrict__ done, const double *__restrict__ rhs, const double *__restrict__ extra,
-    PcgState *st, const double *__restrict__ slab_in, int nblocks_in) {
+    PcgState *st, const double *__restrict__ slab_in, int nblocks_in, int stride_in, double *__restrict__ xupd) {
   // MODE 0: y = alpha A x + beta y.  1: y = A x, partials of <y,x>, <x,x>.  2: Jacobi sweep.
   // MODE 3 (fused CG, first kernel of a step): partials of <A x, x>, <x,x> only, nothing stored.
   // MODE 4 (second kernel): rhs (= y = the residual r) <- r - alpha A x with alpha = gamma / <A x, x> from slab_in;
   //                         partials of <r,z>, <r,r>; `extra` = 1/diag when the Jacobi preconditioner is on.
+  // MODE 5: MODE 4 plus xupd += alpha x (the CG solution update) and the partial of <xupd,xupd> (row-block solver).
   if (done != nullptr && *done != 0) return;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   constexpr int C = kSweepC, NS = kSweepNS;
@@ -1028,7 +1029,7 @@ __global__ __launch_bounds__(kThreads) void spmv_sweep_kernel(
   double *ring = reinterpret_cast<double *>(smem_raw);            // NS slabs of sw entries
   unsigned *smask = reinterpret_cast<unsigned *>(ring + NS * sw);   // npat
   const int tid = threadIdx.x;
-  if (MODE == 3 || MODE == 4) {
+  if (MODE >= 3) {
     const bool leader = (blockIdx.x == 0 && tid == 0);
     if (st->done != 0) return;
     if (st->pending != 0) {   // the previous kernel finished its x update and asked to stop
@@ -1039,7 +1040,7 @@ __global__ __launch_bounds__(kThreads) void spmv_sweep_kernel(
       const int cand = st->cand;
       if (cand != 0) {   // settle the relative-change test with <x,x> of the update that has just landed
         double v[1];
-        reduce_slab<1, kThreads>(slab_in, nblocks_in, kSlabStride, v, ring);
+        reduce_slab<1, kThreads>(slab_in, nblocks_in, stride_in, v, ring);
         const double ratio = st->alpha * st->alpha * st->pp / v[0];
         __syncthreads();   // every thread has read the state before the leader touches it
         if (ratio < st->eps) {
@@ -1054,7 +1055,7 @@ __global__ __launch_bounds__(kThreads) void spmv_sweep_kernel(
       }
     } else {
       double d[2];
-      reduce_slab<2, kThreads>(slab_in, nblocks_in, kSlabStride, d, ring);
+      reduce_slab<2, kThreads>(slab_in, nblocks_in, stride_in, d, ring);
       const double sdotp = d[0], gamma = st->gamma;
       __syncthreads();
       if (sdotp == 0.0) {
@@ -1073,7 +1074,7 @@ __global__ __launch_bounds__(kThreads) void spmv_sweep_kernel(
   for (int i = tid; i < npat; i += kThreads) smask[i] = pmask[i];
   const int nb = gridDim.x;   // multiple of 8; blocks of one XCD take neighbouring chunks of a plane (shared halos in its L2)
   const int lid = (blockIdx.x & 7) * (nb >> 3) + (blockIdx.x >> 3);
-  double acc0 = 0.0, acc1 = 0.0;
+  double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
   if (lid < S.ncp * S.nseg) {
     // all row / column indices fit 29 bits here (plan_sweep): 32-bit arithmetic throughout, one v_med3 per clamp
     const int nr = (int)nrows;
@@ -1114,8 +1115,8 @@ __global__ __launch_bounds__(kThreads) void spmv_sweep_kernel(
       const int g = min(row_of(j), rlast);
       return *reinterpret_cast<const d2_t *>(reinterpret_cast<const char *>(p) + ((unsigned)g << 3));
     };
-    const double *aux = (MODE == 2 || MODE == 4) ? rhs : (MODE == 0 && beta != 0.0) ? y : nullptr;
-    constexpr bool kExtra = (MODE == 2 || MODE == 4);
+    const double *aux = (MODE == 2 || MODE >= 4) ? rhs : (MODE == 0 && beta != 0.0) ? y : nullptr;
+    constexpr bool kExtra = (MODE == 2 || MODE >= 4);
 
     // Three register stages, each used in place: stage (k mod 3) holds slab k+2 at step k, is written to the
     // ring and at once re-loaded with slab k+5 -- no register-to-register rotation (a move of a register
@@ -1130,23 +1131,27 @@ __global__ __launch_bounds__(kThreads) void spmv_sweep_kernel(
     // issue order as in the steady state (ids/aux of a plane, then the slab two planes further): the compiler
     // derives "how many younger loads may stay in flight" from the worst path into the loop, the prologue included
     d2_t ax0 = {0.0, 0.0}, ax1 = ax0, ax2 = ax0, ex0 = ax0, ex1 = ax0, ex2 = ax0;
+    d2_t xu0 = ax0, xu1 = ax0, xu2 = ax0;
     unsigned id0 = load_ids(k0);
     if (aux) ax0 = load_pair(aux, k0);
     if (kExtra && extra) ex0 = load_pair(extra, k0);
+    if (MODE == 5) xu0 = load_pair(xupd, k0);
     load_slab(k0 + 2, st0);
     unsigned id1 = load_ids(k0 + 1);
     if (aux) ax1 = load_pair(aux, k0 + 1);
     if (kExtra && extra) ex1 = load_pair(extra, k0 + 1);
+    if (MODE == 5) xu1 = load_pair(xupd, k0 + 1);
     load_slab(k0 + 3, st1);
     unsigned id2 = load_ids(k0 + 2);
     if (aux) ax2 = load_pair(aux, k0 + 2);
     if (kExtra && extra) ex2 = load_pair(extra, k0 + 2);
+    if (MODE == 5) xu2 = load_pair(xupd, k0 + 2);
     load_slab(k0 + 4, st2);
     __syncthreads();
 
-    auto step = [&](int k, d2_t(&st)[NL], unsigned &idr, d2_t &axr, d2_t &exr) {
+    auto step = [&](int k, d2_t(&st)[NL], unsigned &idr, d2_t &axr, d2_t &exr, d2_t &xur) {
       const unsigned id0 = idr;
-      const d2_t ax0 = axr, ex0 = exr;
+      const d2_t ax0 = axr, ex0 = exr, xu0 = xur;
       const int jb = (k - k0 + 1) & (NS - 1);   // ring slot of plane k
       if (live(k)) {
         const int g = row_of(k);
@@ -1202,7 +1207,19 @@ __global__ __launch_bounds__(kThreads) void spmv_sweep_kernel(
             out.y = xb + rb / db;
             acc0 += ra * ra;
             if (two) acc0 += rb * rb;
-          } else if (MODE == 4) {
+          } else if (MODE >= 4) {
+            if (MODE == 5) {
+              d2_t xv = xu0;
+              xv.x += alpha * xa;
+              xv.y += alpha * xb;
+              acc2 += xv.x * xv.x;
+              if (two) {
+                acc2 += xv.y * xv.y;
+                *reinterpret_cast<d2_t *>(reinterpret_cast<char *>(xupd) + ((unsigned)g << 3)) = xv;
+              } else {
+                *reinterpret_cast<double *>(reinterpret_cast<char *>(xupd) + ((unsigned)g << 3)) = xv.x;
+              }
+            }
             double ra = ax0.x, rb = ax0.y;
             ra -= alpha * s0;
             rb -= alpha * s1;
@@ -1231,22 +1248,24 @@ __global__ __launch_bounds__(kThreads) void spmv_sweep_kernel(
       idr = load_ids(k + 3);
       if (aux) axr = load_pair(aux, k + 3);
       if (kExtra && extra) exr = load_pair(extra, k + 3);
+      if (MODE == 5) xur = load_pair(xupd, k + 3);
       load_slab(k + 5, st);
       __syncthreads();
     };
     for (int k = k0; k < k1; k += 3) {   // straight-line body: steps at or behind k1 compute nothing (live() is false)
-      step(k, st0, id0, ax0, ex0);
-      step(k + 1, st1, id1, ax1, ex1);
-      step(k + 2, st2, id2, ax2, ex2);
+      step(k, st0, id0, ax0, ex0, xu0);
+      step(k + 1, st1, id1, ax1, ex1, xu1);
+      step(k + 2, st2, id2, ax2, ex2, xu2);
     }
   }
   if (MODE != 0) {
     __syncthreads();
-    double w[2] = {acc0, acc1};
-    block_sum<2, kThreads>(w, ring);
+    double w[3] = {acc0, acc1, acc2};
+    block_sum<3, kThreads>(w, ring);
     if (threadIdx.x == 0) {
       slab[0 * kSlabStride + blockIdx.x] = w[0];
       if (MODE != 2) slab[1 * kSlabStride + blockIdx.x] = w[1];
+      if (MODE == 5) slab[2 * kSlabStride + blockIdx.x] = w[2];
     }
   }
 }
@@ -1254,7 +1273,8 @@ __global__ __launch_bounds__(kThreads) void spmv_sweep_kernel(
 template <int MODE>
 static int launch_sweep(const mk_matrix *A, double alpha, const double *x, double beta, double *y, double *slab,
                         const int *done, int *nblocks, const double *rhs = nullptr, const double *extra = nullptr,
-                        PcgState *st = nullptr, const double *slab_in = nullptr, int nblocks_in = 0) {
+                        PcgState *st = nullptr, const double *slab_in = nullptr, int nblocks_in = 0, int stride_in = kSlabStride,
+                        double *xupd = nullptr) {
   Context &c = ctx();
   if (!A->sweep) return fail(MK_ERR_UNSUPPORTED, "spmv: the sweep kernel needs rows that are sub-lists of one pattern with offsets a*P + b");
   SweepArgs S = *A->sweep;
@@ -1284,7 +1304,7 @@ static int launch_sweep(const mk_matrix *A, double alpha, const double *x, doubl
   case NLL:                                                                                                                \
     hipLaunchKernelGGL((spmv_sweep_kernel<MODE, NLL>), dim3((unsigned)blocks), dim3(kThreads), lds, c.stream, S, A->etab, A->nrows, \
                        A->ncols, A->pat, A->pmask, A->npat, x, y, alpha, beta, slab, done, rhs, extra, st, slab_in,       \
-                       nblocks_in);                                                                                        \
+                       nblocks_in, stride_in, xupd);                                                                                        \
     break;
   switch (nl) {
     MK_LAUNCH_SW(2)
@@ -1495,6 +1515,11 @@ int launch_sweep_cg_dots(const mk_matrix *A, const double *p, double *slab_out, 
 int launch_sweep_cg_resid(const mk_matrix *A, const double *p, double *r, const double *dinv, const double *slab_in,
                           int nblocks_in, double *slab_out, PcgState *st, int *nblocks) {
   return launch_sweep<4>(A, 0.0, p, 0.0, r, slab_out, nullptr, nblocks, r, dinv, st, slab_in, nblocks_in);
+}
+
+int launch_sweep_cg_resid_x(const mk_matrix *A, const double *p, double *r, double *x, const double *dinv, const double *slab_in,
+                            int nblocks_in, int stride_in, double *slab_out, PcgState *st, int *nblocks) {
+  return launch_sweep<5>(A, 0.0, p, 0.0, r, slab_out, nullptr, nblocks, r, dinv, st, slab_in, nblocks_in, stride_in, x);
 }
 
 int launch_spmv_dot(const mk_matrix *A, const double *x, double *y, double *slab, const int *done, int *nblocks) {

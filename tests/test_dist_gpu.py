@@ -87,6 +87,41 @@ def test_dist_pcg_matches_oracle(world, precond):
     assert np.allclose(hist[:m], o["rel_norms"][:m], rtol=1e-8)
 
 
+@pytest.mark.parametrize("world,precond", [(1, 0), (2, 1), (3, 0), (4, 1)])
+def test_dist_pcg_fused_sweep_step(world, precond):
+    """constant-coefficient grid: the diag blocks run on the sweep kernel and the solver takes the fused step
+    (A p recomputed, off-rank part applied from a compact buffer, x updated inside the residual sweep)"""
+    dims = (32, 16, 24)
+    rp, ci, v = oracle.stencil_csr(7, *dims)
+    n = rp.size - 1
+    bh = np.random.default_rng(8).normal(size=n)
+    o = oracle.pcg(rp, ci, v, bh, tol=1e-9, precond=precond, maxit=2000, want_norms=True)
+    rs = mkd.slab_row_start(*dims, world)
+    comms = mkd.Comm.local_world(world) if world > 1 else [None]
+    As = _blocks(rp, ci, v, n, rs, comms)
+    for A in As:
+        A.set_spmv_kernel(mk.SPMV_SWEEP)          # small blocks would default to the pattern kernel
+    bs = [A.vector(values=bh[rs[k]:rs[k + 1]]) for k, A in enumerate(As)]
+    xs = [A.vector(fill=0.0) for A in As]
+    Ss = [mk.PCG(max_iter=2000, tol=1e-9, precond=precond, logging=1, check_every=9) for _ in As]
+    res = mkd.dist_pcg_solve(Ss, As, bs, xs)
+    assert all(q == res[0] for q in res)
+    assert res[0]["converged"] == 1 and abs(res[0]["iterations"] - o["iterations"]) <= 2
+    xg = np.concatenate([x.get() for x in xs])
+    assert np.linalg.norm(xg - o["x"]) <= 1e-6 * np.linalg.norm(o["x"])
+    assert np.linalg.norm(bh - oracle.csr_spmv(rp, ci, v, xg)) <= 1.5e-9 * np.linalg.norm(bh)
+    hist = Ss[0].residual_history(4000)
+    m = min(hist.size, o["rel_norms"].size, 30)
+    assert np.allclose(hist[:m], o["rel_norms"][:m], rtol=1e-8)
+    # exactly k iterations
+    xs2 = [A.vector(fill=0.0) for A in As]
+    S2 = [mk.PCG(max_iter=3, tol=1e-30, precond=precond) for _ in As]
+    r2 = mkd.dist_pcg_solve(S2, As, bs, xs2)
+    o2 = oracle.pcg(rp, ci, v, bh, tol=1e-30, precond=precond, maxit=3)
+    assert r2[0]["iterations"] == 3
+    assert np.allclose(np.concatenate([x.get() for x in xs2]), o2["x"], rtol=1e-9, atol=1e-13)
+
+
 def test_dist_pcg_maxit_and_empty_rank():
     rp, ci, v = oracle.stencil_csr(5, 20, 20)
     n = rp.size - 1

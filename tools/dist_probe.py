@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Overhead of the row-block machinery on ONE GPU: CG on nx*ny*nz as a single matrix against the same
+problem cut into `world` z-slabs driven as a local world (device copies instead of RCCL).
+usage: dist_probe.py nx ny nz world [iters]"""
+import os
+import sys
+import time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import iterative_solvers_amd as mk
+from iterative_solvers_amd import distributed as mkd
+
+nx, ny, nz, world = (int(a) for a in sys.argv[1:5])
+iters = int(sys.argv[5]) if len(sys.argv) > 5 else 100
+mk.init(0)
+n = nx * ny * nz
+
+
+def timed(fn):
+    fn(5)
+    mk.synchronize()
+    t0 = time.perf_counter()
+    fn(iters)
+    mk.synchronize()
+    return (time.perf_counter() - t0) / iters * 1e3
+
+
+A = mk.Matrix.stencil(7, nx, ny, nz)
+b, x = mk.Vector(n, fill=1.0), mk.Vector(n, fill=0.0)
+
+
+def single(it):
+    x.fill(0.0)
+    S = mk.PCG(max_iter=it, tol=0.0, logging=0, check_every=50)
+    S.setup(A, b, x)
+    S.solve(A, b, x)
+
+
+ms1 = timed(single)
+del A, b, x
+rs = mkd.slab_row_start(nx, ny, nz, world)
+comms = mkd.Comm.local_world(world)
+As = [mkd.DistMatrix(mk.Matrix.stencil(7, nx, ny, nz, row_begin=int(rs[r]), row_end=int(rs[r + 1])), n, rs, comms[r]) for r in range(world)]
+bs = [a.vector(fill=1.0) for a in As]
+xs = [a.vector(fill=0.0) for a in As]
+
+
+def dist(it):
+    for v in xs:
+        v.fill(0.0)
+    Ss = [mk.PCG(max_iter=it, tol=0.0, logging=0, check_every=50) for _ in As]
+    mkd.dist_pcg_solve(Ss, As, bs, xs)
+
+
+ms2 = timed(dist)
+print(f"{nx}x{ny}x{nz}: single matrix {ms1:.3f} ms/iteration; {world} local ranks {ms2:.3f} ms/iteration "
+      f"({ms2 / world:.3f} ms per rank-iteration)", flush=True)
