@@ -786,7 +786,7 @@ int mk_dist_pcg_solve(int R, mk_pcg **solvers, mk_dist_matrix **A, mk_vector **b
   for (int it = 0; it < S0->max_iter && !stop; it++) {
     MK_D(halo_exchange(R, A, pv.data(), rccl));                                  // on the communication stream over RCCL
     for (int r = 0; r < R; r++) {                                                 // K1a: diag block, overlaps the halo
-      if (fusedv[r]) MK_D(launch_sweep_cg_dots(&A[r]->diag, W[r].p, W[r].slab1, W[r].state, nullptr, 0, &nb1[r]));
+      if (fusedv[r]) MK_D(launch_sweep_cg_dots(&A[r]->diag, W[r].p, W[r].slab1, W[r].state, &nb1[r]));
       else MK_D(launch_spmv_dot(&A[r]->diag, W[r].p, W[r].s, W[r].slab1, &W[r].state->done, &nb1[r]));
     }
     for (int r = 0; r < R; r++) {                                                 // K1b: offd block once the ghosts are in

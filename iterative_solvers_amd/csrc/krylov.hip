@@ -24,9 +24,9 @@
 namespace mk {
 
 static void pcg_release(mk_pcg *S) {
-  dev_free(S->r); dev_free(S->p); dev_free(S->s); dev_free(S->slab1); dev_free(S->slab2); dev_free(S->slab3);
+  dev_free(S->r); dev_free(S->p); dev_free(S->s); dev_free(S->slab1); dev_free(S->slab2);
   dev_free(S->state); dev_free(S->norms);
-  S->r = S->p = S->s = S->slab1 = S->slab2 = S->slab3 = S->norms = nullptr;
+  S->r = S->p = S->s = S->slab1 = S->slab2 = S->norms = nullptr;
   S->state = nullptr;
   for (int k = 0; k < 2; k++)
     if (S->ev[k]) { (void)hipEventDestroy(S->ev[k]); S->ev[k] = nullptr; }
@@ -75,7 +75,6 @@ int mk_pcg_setup(mk_pcg *S, const mk_matrix *A, const mk_vector *b, const mk_vec
   MK_TRY(dev_alloc(&S->s, (size_t)S->n));
   MK_TRY(dev_alloc(&S->slab1, (size_t)kMaxParts * kSlabStride));
   MK_TRY(dev_alloc(&S->slab2, (size_t)kMaxParts * kSlabStride));
-  MK_TRY(dev_alloc(&S->slab3, (size_t)kSlabStride));
   MK_TRY(dev_alloc(&S->state, 1));
   if (S->logging > 0 || S->print_level > 0) {
     S->norms_cap = S->max_iter + 1;
@@ -121,21 +120,22 @@ int mk_pcg_solve(mk_pcg *S, const mk_matrix *A, const mk_vector *b, mk_vector *x
   int nchk = 0;
   bool stop = false;
   // Matrices served by the sweep kernel take the fused step: the sweep runs twice (dots of A p; then
-  // r -= alpha A p with A p recomputed instead of written and re-read) and x += alpha p rides with the p
-  // update: 76 B per row and iteration instead of 90 (s is never stored, p is read twice instead of three
-  // times).  Same recurrences and stopping rule, other summation order of the inner products.
+  // r -= alpha A p with A p recomputed instead of written and re-read, x += alpha p in the same pass since p is
+  // in the LDS window anyway) and K3 is unchanged: 76 B per row and iteration instead of 90 (s is never stored,
+  // p is read twice instead of three times).  Same recurrences and stopping rule, other summation order of the
+  // inner products.
   static const int no_fused = getenv("MK_NO_FUSED_CG") ? atoi(getenv("MK_NO_FUSED_CG")) : 0;
   const bool fused = (A->kernel == MK_SPMV_SWEEP) && !no_fused;
   for (int it = 0; it < S->max_iter && !stop; it++) {
     int nb1 = 0;
     if (fused) {
       int nb2 = 0;
-      MK_TRY(launch_sweep_cg_dots(A, S->p, S->slab1, S->state, S->slab3, vb, &nb1));
-      MK_TRY(launch_sweep_cg_resid(A, S->p, S->r, dinv, S->slab1, nb1, S->slab2, S->state, &nb2));
+      MK_TRY(launch_sweep_cg_dots(A, S->p, S->slab1, S->state, &nb1));
+      MK_TRY(launch_sweep_cg_resid_x(A, S->p, S->r, x->d, dinv, S->slab1, nb1, kSlabStride, S->slab2, S->state, &nb2));
       if (dinv)
-        hipLaunchKernelGGL((pcg_update_px_kernel<true>), dim3(vb), dim3(kVecThreads), 0, c.stream, n, S->r, dinv, S->p, x->d, S->slab2, nb2, kSlabStride, S->two_norm, S->rel_change, S->state, S->norms, S->slab3);
+        hipLaunchKernelGGL((pcg_update_p_kernel<true>), dim3(vb), dim3(kVecThreads), 0, c.stream, n, S->r, dinv, S->p, S->slab2, nb2, kSlabStride, S->two_norm, S->rel_change, S->state, S->norms);
       else
-        hipLaunchKernelGGL((pcg_update_px_kernel<false>), dim3(vb), dim3(kVecThreads), 0, c.stream, n, S->r, dinv, S->p, x->d, S->slab2, nb2, kSlabStride, S->two_norm, S->rel_change, S->state, S->norms, S->slab3);
+        hipLaunchKernelGGL((pcg_update_p_kernel<false>), dim3(vb), dim3(kVecThreads), 0, c.stream, n, S->r, dinv, S->p, S->slab2, nb2, kSlabStride, S->two_norm, S->rel_change, S->state, S->norms);
     } else {
     MK_TRY(launch_spmv_dot(A, S->p, S->s, S->slab1, &S->state->done, &nb1));
     if (dinv) {
@@ -151,7 +151,7 @@ int mk_pcg_solve(mk_pcg *S, const mk_matrix *A, const mk_vector *b, mk_vector *x
       // look at the previous checkpoint first: the GPU stays one batch ahead of the host
       if (pending >= 0) {
         MK_HIP(hipEventSynchronize(S->ev[pending]));
-        if (hst[pending].done != 0 || hst[pending].pending != 0) stop = true;
+        if (hst[pending].done != 0) stop = true;
       }
       if (!stop) {
         MK_HIP(hipMemcpyAsync(&hst[slot], S->state, sizeof(PcgState), hipMemcpyDeviceToHost, c.stream));
@@ -161,7 +161,6 @@ int mk_pcg_solve(mk_pcg *S, const mk_matrix *A, const mk_vector *b, mk_vector *x
       }
     }
   }
-  if (fused) hipLaunchKernelGGL(pcg_fused_finalize_kernel, dim3(1), dim3(kVecThreads), 0, c.stream, S->state, S->slab3, vb);
   MK_HIP(hipGetLastError());
   MK_HIP(hipMemcpyAsync(&hst[0], S->state, sizeof(PcgState), hipMemcpyDeviceToHost, c.stream));
   MK_HIP(hipStreamSynchronize(c.stream));

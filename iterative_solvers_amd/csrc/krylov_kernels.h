@@ -156,92 +156,6 @@ __global__ __launch_bounds__(kVecThreads) void pcg_update_p_kernel(int64_t n, co
   }
 }
 
-// K3 of the fused-sweep variant: the x update rides here (p is read anyway), so the residual kernel before it
-// streams only r.  x += alpha p happens whatever the tests say (it completes the iteration that just ended);
-// a stop is raised as `pending` because late blocks of this very launch must still do their x update, and
-// the relative-change test, which needs <x,x> of the update in flight, is left to the next kernel (`cand`).
-template <bool PRECOND>
-__global__ __launch_bounds__(kVecThreads) void pcg_update_px_kernel(int64_t n, const double *__restrict__ r,
-                                                                    const double *__restrict__ dinv, double *__restrict__ p,
-                                                                    double *__restrict__ x, const double *__restrict__ slab_in,
-                                                                    int nblocks_in, int stride_in, int two_norm, int rel_change,
-                                                                    PcgState *st, double *__restrict__ norms,
-                                                                    double *__restrict__ slab_xx) {
-  if (st->done != 0) return;
-  __shared__ double smem[2 * (kVecThreads / 64)];
-  double d[2];
-  reduce_slab<2, kVecThreads>(slab_in, nblocks_in, stride_in, d, smem);
-  const double gamma_new = d[0];
-  const double i_prod = two_norm ? d[1] : d[0];
-  const double bi_prod = st->bi_prod, eps = st->eps, alpha = st->alpha, gamma_old = st->gamma_old;
-  const bool leader = (blockIdx.x == 0 && threadIdx.x == 0);
-  const bool cand = (i_prod / bi_prod < eps);
-  const bool defer = cand && rel_change && i_prod > 0.0;
-  const bool conv = cand && !defer;
-  const bool tiny_gamma = (gamma_new < DBL_MIN) && (-gamma_new < DBL_MIN);
-  if (leader) {
-    st->gamma = gamma_new;
-    st->i_prod = i_prod;
-    if (norms) norms[st->iter] = sqrt(i_prod / bi_prod);
-    if (conv) { st->converged = 1; st->pending = 1; }
-    else if (tiny_gamma && !defer) { st->breakdown = 3; st->pending = 2; }
-    st->cand = defer ? (tiny_gamma ? 2 : 1) : 0;   // 2: if the deferred test fails, the tiny-gamma breakdown stands
-  }
-  const bool update_p = !(conv || tiny_gamma);
-  const double beta = gamma_new / gamma_old;
-  double v[1] = {0.0};
-  const int64_t n2 = n >> 1;
-  const double2 *r2 = reinterpret_cast<const double2 *>(r);
-  const double2 *d2 = reinterpret_cast<const double2 *>(dinv);
-  double2 *p2 = reinterpret_cast<double2 *>(p);
-  double2 *x2 = reinterpret_cast<double2 *>(x);
-  for (int64_t i = (int64_t)blockIdx.x * kVecThreads + threadIdx.x; i < n2; i += (int64_t)gridDim.x * kVecThreads) {
-    double2 pv = p2[i];
-    double2 xv = x2[i];
-    xv.x += alpha * pv.x; xv.y += alpha * pv.y;
-    x2[i] = xv;
-    v[0] += xv.x * xv.x + xv.y * xv.y;
-    if (update_p) {
-      double2 zv = r2[i];
-      if (PRECOND) { const double2 dv = d2[i]; zv.x *= dv.x; zv.y *= dv.y; }
-      pv.x = beta * pv.x + zv.x;
-      pv.y = beta * pv.y + zv.y;
-      p2[i] = pv;
-    }
-  }
-  if ((n & 1) && leader) {
-    const int64_t i = n - 1;
-    const double pi = p[i];
-    const double xi = x[i] + alpha * pi;
-    x[i] = xi;
-    v[0] += xi * xi;
-    if (update_p) {
-      const double zi = PRECOND ? r[i] * dinv[i] : r[i];
-      p[i] = beta * pi + zi;
-    }
-  }
-  block_sum<1, kVecThreads>(v, smem);
-  if (threadIdx.x == 0) slab_xx[blockIdx.x] = v[0];
-}
-
-// after the last iteration: settle what the next kernel would have settled (pending stop, deferred test)
-static __global__ __launch_bounds__(kVecThreads) void pcg_fused_finalize_kernel(PcgState *st, const double *slab_xx, int nblocks_xx) {
-  __shared__ double smem[kVecThreads / 64];
-  if (st->done != 0) return;
-  double v[1];
-  reduce_slab<1, kVecThreads>(slab_xx, nblocks_xx, kSlabStride, v, smem);
-  if (threadIdx.x == 0) {
-    if (st->pending != 0) {
-      st->done = st->pending;
-    } else if (st->cand != 0) {
-      const double ratio = st->alpha * st->alpha * st->pp / v[0];
-      if (ratio < st->eps) { st->converged = 1; st->done = 1; }
-      else if (st->cand == 2) { st->breakdown = 3; st->done = 2; }
-      st->cand = 0;
-    }
-  }
-}
-
 static __global__ void copy_kernel(double *__restrict__ dst, const double *__restrict__ src, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[i];
 }
@@ -286,7 +200,7 @@ struct mk_pcg {
   // work space (setup)
   int64_t n = 0;
   double *r = nullptr, *p = nullptr, *s = nullptr;
-  double *slab1 = nullptr, *slab2 = nullptr, *slab3 = nullptr;
+  double *slab1 = nullptr, *slab2 = nullptr;
   mk::PcgState *state = nullptr;
   double *norms = nullptr;
   int norms_cap = 0;

@@ -89,9 +89,6 @@ struct PcgState {
   int done;        // 0 running, 1 converged, 2 breakdown
   int converged;
   int breakdown;   // 1 zero <s,p>, 2 subnormal alpha, 3 subnormal gamma
-  // fused-sweep variant only (x is updated one kernel later there):
-  int pending;     // stop code raised by the kernel that still had to finish its x update; the next kernel makes it `done`
-  int cand;        // residual test passed, the relative-change test waits for <x,x> of the update in flight
   int pad;
 };
 
@@ -142,7 +139,7 @@ struct mk_matrix {
   unsigned *pmask = nullptr;       // device, npat: which entries of the base pattern each pattern keeps
   mk::SweepEntry *etab = nullptr;  // device, 32 entries
   bool sweep_auto = false;         // enough parallelism for the sweep kernel to be the default
-  mutable int sweep_bpc[6] = {0, 0, 0, 0, 0, 0};
+  mutable int sweep_bpc[5] = {0, 0, 0, 0, 0};
   int npat = 0, pml = 0;
   int max_off = 0;                 // largest |column - row| over all patterns
   // split kernel: chunk c covers entries [c*kSplitChunk, (c+1)*kSplitChunk); chunk_row[c] = first row starting in it
@@ -177,16 +174,12 @@ int launch_spmv_dot(const mk_matrix *A, const double *x, double *y, double *slab
 int launch_jacobi_sweep(const mk_matrix *A, const double *rhs, const double *extra, const double *xold, double *xnew,
                         double *slab, const int *done, int *nblocks);
 
-// fused CG on matrices served by the sweep kernel (two more modes of it; the scalar logic of the step runs in
-// their prologues).  dots: partials of <A p, p>, <p,p> into slab_out, nothing stored; first settles a pending
-// relative-change test from slab_xx.  resid: r -= alpha * A p with alpha from slab_in, partials of <r,z>, <r,r>.
-int launch_sweep_cg_dots(const mk_matrix *A, const double *p, double *slab_out, PcgState *st, const double *slab_xx,
-                         int nblocks_xx, int *nblocks);
-int launch_sweep_cg_resid(const mk_matrix *A, const double *p, double *r, const double *dinv, const double *slab_in,
-                          int nblocks_in, double *slab_out, PcgState *st, int *nblocks);
-
-// row-block solver: as resid, plus x += alpha p and the partial of <x,x> (component 2); alpha from slab_in with
-// the given stride between its two components (1 for an all-reduced pair)
+// fused CG on matrices served by the sweep kernel: two more modes of it, the scalar logic of the step (alpha,
+// breakdown tests, iteration counter) runs in the second one's prologue.
+//   dots   : partials of <A p, p>, <p,p> into slab_out, nothing stored
+//   resid_x: r -= alpha * A p with alpha = gamma / <A p,p> from slab_in (stride_in between its two components: 1 for
+//            an all-reduced pair), x += alpha p, partials of <r,z>, <r,r>, <x,x>
+int launch_sweep_cg_dots(const mk_matrix *A, const double *p, double *slab_out, PcgState *st, int *nblocks);
 int launch_sweep_cg_resid_x(const mk_matrix *A, const double *p, double *r, double *x, const double *dinv, const double *slab_in,
                             int nblocks_in, int stride_in, double *slab_out, PcgState *st, int *nblocks);
 

@@ -1019,9 +1019,9 @@ __global__ __launch_bounds__(kThreads) void spmv_sweep_kernel(
     PcgState *st, const double *__restrict__ slab_in, int nblocks_in, int stride_in, double *__restrict__ xupd) {
   // MODE 0: y = alpha A x + beta y.  1: y = A x, partials of <y,x>, <x,x>.  2: Jacobi sweep.
   // MODE 3 (fused CG, first kernel of a step): partials of <A x, x>, <x,x> only, nothing stored.
-  // MODE 4 (second kernel): rhs (= y = the residual r) <- r - alpha A x with alpha = gamma / <A x, x> from slab_in;
-  //                         partials of <r,z>, <r,r>; `extra` = 1/diag when the Jacobi preconditioner is on.
-  // MODE 5: MODE 4 plus xupd += alpha x (the CG solution update) and the partial of <xupd,xupd> (row-block solver).
+  // MODE 4 (second kernel; x is CG's p): alpha = gamma / <A x, x> from slab_in (K2's prologue), then
+  //         rhs (= y = the residual r) <- r - alpha A x, xupd += alpha x (the solution update: x is in the window
+  //         anyway), partials of <r,z>, <r,r>, <xupd,xupd>; `extra` = 1/diag when the Jacobi preconditioner is on.
   if (done != nullptr && *done != 0) return;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   constexpr int C = kSweepC, NS = kSweepNS;
@@ -1030,30 +1030,9 @@ __global__ __launch_bounds__(kThreads) void spmv_sweep_kernel(
   unsigned *smask = reinterpret_cast<unsigned *>(ring + NS * sw);   // npat
   const int tid = threadIdx.x;
   if (MODE >= 3) {
-    const bool leader = (blockIdx.x == 0 && tid == 0);
     if (st->done != 0) return;
-    if (st->pending != 0) {   // the previous kernel finished its x update and asked to stop
-      if (leader) st->done = st->pending;
-      return;
-    }
-    if (MODE == 3) {
-      const int cand = st->cand;
-      if (cand != 0) {   // settle the relative-change test with <x,x> of the update that has just landed
-        double v[1];
-        reduce_slab<1, kThreads>(slab_in, nblocks_in, stride_in, v, ring);
-        const double ratio = st->alpha * st->alpha * st->pp / v[0];
-        __syncthreads();   // every thread has read the state before the leader touches it
-        if (ratio < st->eps) {
-          if (leader) { st->converged = 1; st->done = 1; st->cand = 0; }
-          return;
-        }
-        if (cand == 2) {
-          if (leader) { st->breakdown = 3; st->done = 2; st->cand = 0; }
-          return;
-        }
-        if (leader) st->cand = 0;
-      }
-    } else {
+    if (MODE == 4) {   // K2's prologue
+      const bool leader = (blockIdx.x == 0 && tid == 0);
       double d[2];
       reduce_slab<2, kThreads>(slab_in, nblocks_in, stride_in, d, ring);
       const double sdotp = d[0], gamma = st->gamma;
@@ -1115,8 +1094,8 @@ __global__ __launch_bounds__(kThreads) void spmv_sweep_kernel(
       const int g = min(row_of(j), rlast);
       return *reinterpret_cast<const d2_t *>(reinterpret_cast<const char *>(p) + ((unsigned)g << 3));
     };
-    const double *aux = (MODE == 2 || MODE >= 4) ? rhs : (MODE == 0 && beta != 0.0) ? y : nullptr;
-    constexpr bool kExtra = (MODE == 2 || MODE >= 4);
+    const double *aux = (MODE == 2 || MODE == 4) ? rhs : (MODE == 0 && beta != 0.0) ? y : nullptr;
+    constexpr bool kExtra = (MODE == 2 || MODE == 4);
 
     // Three register stages, each used in place: stage (k mod 3) holds slab k+2 at step k, is written to the
     // ring and at once re-loaded with slab k+5 -- no register-to-register rotation (a move of a register
@@ -1135,17 +1114,17 @@ __global__ __launch_bounds__(kThreads) void spmv_sweep_kernel(
     unsigned id0 = load_ids(k0);
     if (aux) ax0 = load_pair(aux, k0);
     if (kExtra && extra) ex0 = load_pair(extra, k0);
-    if (MODE == 5) xu0 = load_pair(xupd, k0);
+    if (MODE == 4) xu0 = load_pair(xupd, k0);
     load_slab(k0 + 2, st0);
     unsigned id1 = load_ids(k0 + 1);
     if (aux) ax1 = load_pair(aux, k0 + 1);
     if (kExtra && extra) ex1 = load_pair(extra, k0 + 1);
-    if (MODE == 5) xu1 = load_pair(xupd, k0 + 1);
+    if (MODE == 4) xu1 = load_pair(xupd, k0 + 1);
     load_slab(k0 + 3, st1);
     unsigned id2 = load_ids(k0 + 2);
     if (aux) ax2 = load_pair(aux, k0 + 2);
     if (kExtra && extra) ex2 = load_pair(extra, k0 + 2);
-    if (MODE == 5) xu2 = load_pair(xupd, k0 + 2);
+    if (MODE == 4) xu2 = load_pair(xupd, k0 + 2);
     load_slab(k0 + 4, st2);
     __syncthreads();
 
@@ -1207,8 +1186,8 @@ __global__ __launch_bounds__(kThreads) void spmv_sweep_kernel(
             out.y = xb + rb / db;
             acc0 += ra * ra;
             if (two) acc0 += rb * rb;
-          } else if (MODE >= 4) {
-            if (MODE == 5) {
+          } else if (MODE == 4) {
+            {
               d2_t xv = xu0;
               xv.x += alpha * xa;
               xv.y += alpha * xb;
@@ -1248,7 +1227,7 @@ __global__ __launch_bounds__(kThreads) void spmv_sweep_kernel(
       idr = load_ids(k + 3);
       if (aux) axr = load_pair(aux, k + 3);
       if (kExtra && extra) exr = load_pair(extra, k + 3);
-      if (MODE == 5) xur = load_pair(xupd, k + 3);
+      if (MODE == 4) xur = load_pair(xupd, k + 3);
       load_slab(k + 5, st);
       __syncthreads();
     };
@@ -1265,7 +1244,7 @@ __global__ __launch_bounds__(kThreads) void spmv_sweep_kernel(
     if (threadIdx.x == 0) {
       slab[0 * kSlabStride + blockIdx.x] = w[0];
       if (MODE != 2) slab[1 * kSlabStride + blockIdx.x] = w[1];
-      if (MODE == 5) slab[2 * kSlabStride + blockIdx.x] = w[2];
+      if (MODE == 4) slab[2 * kSlabStride + blockIdx.x] = w[2];
     }
   }
 }
@@ -1507,19 +1486,13 @@ int launch_jacobi_sweep(const mk_matrix *A, const double *rhs, const double *ext
   return launch_stream<2>(A, 1.0, xold, 0.0, xnew, slab, done, nblocks, rhs, extra);
 }
 
-int launch_sweep_cg_dots(const mk_matrix *A, const double *p, double *slab_out, PcgState *st, const double *slab_xx,
-                         int nblocks_xx, int *nblocks) {
-  return launch_sweep<3>(A, 1.0, p, 0.0, nullptr, slab_out, nullptr, nblocks, nullptr, nullptr, st, slab_xx, nblocks_xx);
-}
-
-int launch_sweep_cg_resid(const mk_matrix *A, const double *p, double *r, const double *dinv, const double *slab_in,
-                          int nblocks_in, double *slab_out, PcgState *st, int *nblocks) {
-  return launch_sweep<4>(A, 0.0, p, 0.0, r, slab_out, nullptr, nblocks, r, dinv, st, slab_in, nblocks_in);
+int launch_sweep_cg_dots(const mk_matrix *A, const double *p, double *slab_out, PcgState *st, int *nblocks) {
+  return launch_sweep<3>(A, 1.0, p, 0.0, nullptr, slab_out, nullptr, nblocks, nullptr, nullptr, st);
 }
 
 int launch_sweep_cg_resid_x(const mk_matrix *A, const double *p, double *r, double *x, const double *dinv, const double *slab_in,
                             int nblocks_in, int stride_in, double *slab_out, PcgState *st, int *nblocks) {
-  return launch_sweep<5>(A, 0.0, p, 0.0, r, slab_out, nullptr, nblocks, r, dinv, st, slab_in, nblocks_in, stride_in, x);
+  return launch_sweep<4>(A, 0.0, p, 0.0, r, slab_out, nullptr, nblocks, r, dinv, st, slab_in, nblocks_in, stride_in, x);
 }
 
 int launch_spmv_dot(const mk_matrix *A, const double *x, double *y, double *slab, const int *done, int *nblocks) {
