@@ -3,11 +3,13 @@
  * (src/solvers.c:98-152 flags, :762-772 result lines), calling libmi355_krylov.so where the
  * reference calls HYPRE.  One process drives one MI355X.
  *
+ *   -solver 6   BiCGSTAB, no preconditioner                                (solvers.c:517-564)
  *   -solver 50  PCG, no preconditioner, two-norm + rel_change stopping   (solvers.c:724-776)
  *   -solver 51  PCG with diagonal scaling      (extension)
  *   -solver 70  plain Jacobi iteration          (extension)
- * The other ids of the reference (AMG, ILU, ParaSails, GMRES, BiCGSTAB, ...; solvers.c:465-1548)
- * are HYPRE preconditioner stacks outside this library's scope and are refused by name.
+ * The other ids of the reference (AMG, ILU, ParaSails, GMRES, ...; solvers.c:465-1548) are HYPRE
+ * preconditioner stacks outside this library's scope and are refused by name.
+ * -p <file> [-id <gpu>] samples the board power while the solver runs (cpower.h, solvers.c:537-546).
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -15,6 +17,7 @@
 #include <time.h>
 
 #include "sparse_matrix.h"
+#include "power.h"
 
 static double now_s(void) {
   struct timespec t;
@@ -47,6 +50,8 @@ static void usage(const char *argv0) {
   printf("                           50 - PCG\n");
   printf("                           51 - PCG + diagonal scaling\n");
   printf("                           70 - Jacobi iteration\n");
+  printf("  -p <file>              : append the board power in watts to <file>, 10 samples a second, while the solver runs\n");
+  printf("  -id <device>           : GPU whose power is sampled (default: the one in use)\n");
   printf("  -cache                 : keep <matrix.mtx>.mkcsr (binary CSR) and load it instead of the text when present\n");
   printf("  -print_system          : write the assembled CSR back to IJ.out.A as text\n\n");
 }
@@ -55,7 +60,8 @@ int main(int argc, char *argv[]) {
   int maxit = 1000, prnt_info = 2, precond_log = 1, niter = 1, solver_id = 0, print_system = 0, dev = 0, comp_id = 0, use_cache = 0;
   double tol = 1e-6;
   const char *mtx = NULL, *bfile = NULL, *xfile = NULL, *pow_file = NULL;
-  (void)precond_log; (void)comp_id; (void)pow_file;
+  (void)precond_log;
+  int have_comp_id = 0;
   for (int i = 1; i < argc;) {
     const char *a = argv[i];
     const int has = i + 1 < argc;
@@ -64,7 +70,7 @@ int main(int argc, char *argv[]) {
     else if (!strcmp(a, "-log") && has) { prnt_info = atoi(argv[i + 1]); i += 2; }
     else if (!strcmp(a, "-niter") && has) { niter = atoi(argv[i + 1]); i += 2; }
     else if (!strcmp(a, "-padding")) { i += 1; }                       /* parsed and ignored by the reference too (:115-117) */
-    else if (!strcmp(a, "-id") && has) { comp_id = atoi(argv[i + 1]); i += 2; }
+    else if (!strcmp(a, "-id") && has) { comp_id = atoi(argv[i + 1]); have_comp_id = 1; i += 2; }
     else if (!strcmp(a, "-precond_log") && has) { precond_log = atoi(argv[i + 1]); i += 2; }
     else if (!strcmp(a, "-solver") && has) { solver_id = atoi(argv[i + 1]); i += 2; }
     else if (!strcmp(a, "-mtx") && has) { mtx = argv[i + 1]; i += 2; }
@@ -154,6 +160,14 @@ int main(int argc, char *argv[]) {
     free_csr(&csr);
   }
 
+  /* power sampling brackets setup + solve as the reference's c_popen / c_pclose pair does (solvers.c:537-546) */
+  power_sampler *sampler = NULL;
+  if (pow_file) {
+    char bus[64];
+    CK(mk_get_device_pci_bus_id(have_comp_id ? comp_id : -1, bus, (int)sizeof bus));
+    if (power_sampler_start(bus, pow_file, 100, &sampler) != 0) sampler = NULL;
+  }
+
   long long num_iterations = 0;
   double final_res_norm = 0.0, walltime;
   if (solver_id == 50 || solver_id == 51) {
@@ -216,6 +230,12 @@ int main(int argc, char *argv[]) {
   printf("Iterations = %lld\n", num_iterations);                      /* :770 */
   printf("Final Relative Residual Norm = %e\n", final_res_norm);      /* :771 */
   printf("\n");
+  if (sampler) {
+    double mean_w = 0.0, joules = 0.0;
+    int ns = 0;
+    power_sampler_stop(sampler, &mean_w, &joules, &ns);
+    printf("Power samples = %d, mean board power = %.1f W, energy = %.1f J\n", ns, mean_w, joules);
+  }
   /* extra lines the reference does not print: rate, for scripts/grep_res.sh-style scraping */
   if (walltime > 0.0 && num_iterations > 0) printf("Iterations per second = %f\n", (double)num_iterations * niter / walltime);
 

@@ -74,6 +74,9 @@ int mk_finalize(void);
 const char *mk_last_error_string(void);
 /* the hipStream_t every kernel of this library is launched on (for HIP-event timing) */
 void *mk_get_stream(void);
+/* "0000:c1:00.0" of a GPU (device_id < 0: the one mk_init selected); host/power.c finds the hwmon power node with it
+ * (the reference samples `nvidia-smi -i <id>`, cpower.h:124-130) */
+int mk_get_device_pci_bus_id(int device_id, char *out, int capacity);
 int mk_synchronize(void);
 /* HIP-event timers on that stream: start, stop, then elapsed (milliseconds, synchronises) */
 int mk_timer_start(void);

@@ -42,7 +42,7 @@ PRECOND_NONE, PRECOND_JACOBI = 0, 1
 
 # every symbol include/mk_krylov.h declares (tests check the library exports all of them)
 EXPORTS = [
-    "mk_init", "mk_finalize", "mk_last_error_string", "mk_get_stream", "mk_synchronize",
+    "mk_init", "mk_finalize", "mk_last_error_string", "mk_get_stream", "mk_get_device_pci_bus_id", "mk_synchronize",
     "mk_timer_start", "mk_timer_stop",
     "mk_sort_coo_row", "mk_coo_to_csr",
     "mk_matrix_from_coo", "mk_matrix_from_csr", "mk_matrix_from_device_coo", "mk_matrix_destroy",

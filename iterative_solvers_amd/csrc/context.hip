@@ -86,6 +86,16 @@ int mk_finalize(void) {
 
 void *mk_get_stream(void) { return ctx().ready ? (void *)ctx().stream : nullptr; }
 
+int mk_get_device_pci_bus_id(int device_id, char *out, int capacity) {
+  if (!out || capacity < 16) return fail(MK_ERR_INVALID, "mk_get_device_pci_bus_id: buffer of at least 16 bytes needed");
+  if (device_id < 0) {
+    if (!ctx().ready) return fail(MK_ERR_NOT_INIT, "mk_init() not called");
+    device_id = ctx().device;
+  }
+  MK_HIP(hipDeviceGetPCIBusId(out, capacity, device_id));
+  return MK_OK;
+}
+
 int mk_synchronize(void) {
   MK_REQUIRE_INIT();
   MK_HIP(hipStreamSynchronize(ctx().stream));

@@ -205,6 +205,27 @@ def test_driver_bicgstab_output_lines(tmp_path):
 
 
 @pytest.mark.gpu
+def test_driver_power_sampling(tmp_path):
+    """-p <file>: one number (watts) per line while the solver runs, as the reference's nvidia-smi loop writes
+    (cpower.h:124-130); read from the amdgpu hwmon node here.  A box that hides the node makes the driver say
+    so and solve without sampling."""
+    mtx = tmp_path / "poisson.mtx"
+    _write_poisson(mtx, 200, 200)
+    pw = tmp_path / "power.txt"
+    out = subprocess.run([os.path.join(HOST, "solver"), "-solver", "50", "-mtx", str(mtx), "-tol", "1e-12", "-maxit", "20000",
+                          "-niter", "3", "-p", str(pw)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert re.search(r"^Iterations = \d+$", out.stdout, re.M)
+    if "power sampling:" in out.stderr:
+        pytest.skip("no readable hwmon power node on this box: " + out.stderr.strip().splitlines()[-1])
+    m = re.search(r"^Power samples = (\d+), mean board power = ([0-9.]+) W, energy = ([0-9.]+) J$", out.stdout, re.M)
+    assert m and int(m.group(1)) >= 1
+    vals = [float(l) for l in open(pw).read().split()]
+    assert len(vals) == int(m.group(1)) and all(10.0 < v < 2000.0 for v in vals)
+    assert abs(np.mean(vals) - float(m.group(2))) < 0.1
+
+
+@pytest.mark.gpu
 def test_driver_binary_cache(tmp_path):
     mtx = tmp_path / "poisson.mtx"
     _write_poisson(mtx, 40, 40, shuffle_seed=2)
