@@ -4,6 +4,7 @@
  * reference calls HYPRE.  One process drives one MI355X.
  *
  *   -solver 6   BiCGSTAB, no preconditioner                                (solvers.c:517-564)
+ *   -solver 40  CGNR, no preconditioner                                    (solvers.c:864-906)
  *   -solver 50  PCG, no preconditioner, two-norm + rel_change stopping   (solvers.c:724-776)
  *   -solver 51  PCG with diagonal scaling      (extension)
  *   -solver 70  plain Jacobi iteration          (extension)
@@ -47,6 +48,7 @@ static void usage(const char *argv0) {
   printf("  -dev <id>              : GPU to use (default 0)\n");
   printf("  -solver <ID>           : solver ID\n");
   printf("                           6  - BiCGSTAB\n");
+  printf("                           40 - CGNR\n");
   printf("                           50 - PCG\n");
   printf("                           51 - PCG + diagonal scaling\n");
   printf("                           70 - Jacobi iteration\n");
@@ -84,9 +86,9 @@ int main(int argc, char *argv[]) {
     else i += 1;                                                      /* unknown flags are skipped (:149-151) */
   }
   if (!mtx) { usage(argv[0]); return 1; }
-  if (solver_id != 6 && solver_id != 50 && solver_id != 51 && solver_id != 70) {
+  if (solver_id != 6 && solver_id != 40 && solver_id != 50 && solver_id != 51 && solver_id != 70) {
     printf("Invalid solver id specified.\n");
-    fprintf(stderr, "solver %d is a HYPRE preconditioner/solver stack outside this library; use 6, 50, 51 or 70\n", solver_id);
+    fprintf(stderr, "solver %d is a HYPRE preconditioner/solver stack outside this library; use 6, 40, 50, 51 or 70\n", solver_id);
     return 1;
   }
 
@@ -209,6 +211,23 @@ int main(int argc, char *argv[]) {
     CK(mk_bicgstab_get_num_iterations(solver, &num_iterations));      /* :553 */
     CK(mk_bicgstab_get_final_relative_residual_norm(solver, &final_res_norm)); /* :554 */
     CK(mk_bicgstab_destroy(solver));                                  /* :563 */
+  } else if (solver_id == 40) {
+    mk_cgnr *solver = NULL;
+    CK(mk_cgnr_create(&solver));                                      /* :869 */
+    CK(mk_cgnr_set_max_iter(solver, maxit));                          /* :872 */
+    CK(mk_cgnr_set_tol(solver, tol));                                 /* :873 */
+    CK(mk_cgnr_set_logging(solver, 1));                               /* :874 */
+    CK(mk_cgnr_setup(solver, A, b, x));                               /* :877 */
+    CK(mk_synchronize());
+    double t = -now_s();                                              /* :882 */
+    for (int i = 0; i < niter; i++) CK(mk_cgnr_solve(solver, A, b, x)); /* :883-884 */
+    CK(mk_synchronize());
+    t += now_s();
+    walltime = t;
+    printf("\nCGNR Solve time = %f seconds\n\n", walltime);          /* :892 */
+    CK(mk_cgnr_get_num_iterations(solver, &num_iterations));          /* :895 */
+    CK(mk_cgnr_get_final_relative_residual_norm(solver, &final_res_norm)); /* :896 */
+    CK(mk_cgnr_destroy(solver));                                      /* :905 */
   } else {
     mk_jacobi *solver = NULL;
     CK(mk_jacobi_create(&solver));

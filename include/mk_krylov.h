@@ -66,6 +66,7 @@ typedef struct mk_vector mk_vector;   /* HYPRE_IJVector / HYPRE_ParVector (solve
 typedef struct mk_coo mk_coo;         /* a COO matrix resident in device memory */
 typedef struct mk_pcg mk_pcg;         /* HYPRE_Solver for PCG (solvers.c:65,729) */
 typedef struct mk_bicgstab mk_bicgstab;   /* HYPRE_Solver for BiCGSTAB (solvers.c:65,524) */
+typedef struct mk_cgnr mk_cgnr;           /* HYPRE_Solver for CGNR (solvers.c:65,869) */
 typedef struct mk_jacobi mk_jacobi;   /* extension: plain Jacobi iteration (no reference counterpart) */
 
 /* ---- life cycle: HYPRE_Init() / HYPRE_Finalize() (solvers.c:79,1560) ------------------- */
@@ -195,6 +196,25 @@ int mk_bicgstab_get_converged(const mk_bicgstab *solver, int *converged, int *br
 /* absolute ||r|| after each iteration (needs logging > 0 at setup); returns the number of entries written */
 int mk_bicgstab_get_residual_history(const mk_bicgstab *solver, double *norms, int capacity);
 int mk_bicgstab_destroy(mk_bicgstab *solver);
+
+/* ---- CGNR, solver id 40 (solvers.c:864-906), identity preconditioner ------------------------
+ * HYPRE_ParCSRCGNRCreate :869, HYPRE_CGNRSetMaxIter :872, SetTol :873, SetLogging :874, HYPRE_ParCSRCGNRSetup :877,
+ * Solve :884, HYPRE_CGNRGetNumIterations :895, GetFinalRelativeResidualNorm :896, Destroy :905.
+ * CG on A^T A x = A^T b; setup builds A^T on the device.  Stops when <r,r> < tol^2 <b,b> holds for the recomputed
+ * residual b - A x as well (hypre's rule). */
+int mk_cgnr_create(mk_cgnr **solver);
+int mk_cgnr_set_max_iter(mk_cgnr *solver, int max_iter);
+int mk_cgnr_set_tol(mk_cgnr *solver, double tol);
+int mk_cgnr_set_logging(mk_cgnr *solver, int logging);
+int mk_cgnr_set_check_every(mk_cgnr *solver, int iterations);
+int mk_cgnr_setup(mk_cgnr *solver, const mk_matrix *A, const mk_vector *b, const mk_vector *x);
+int mk_cgnr_solve(mk_cgnr *solver, const mk_matrix *A, const mk_vector *b, mk_vector *x);
+int mk_cgnr_get_num_iterations(const mk_cgnr *solver, long long *iterations);
+int mk_cgnr_get_final_relative_residual_norm(const mk_cgnr *solver, double *norm);
+int mk_cgnr_get_converged(const mk_cgnr *solver, int *converged);
+/* ||r|| / ||b|| after each iteration (needs logging > 0 at setup); returns the number of entries written */
+int mk_cgnr_get_residual_history(const mk_cgnr *solver, double *norms, int capacity);
+int mk_cgnr_destroy(mk_cgnr *solver);
 
 /* ---- plain Jacobi iteration, extension solver id 70 --------------- */
 int mk_jacobi_create(mk_jacobi **solver);

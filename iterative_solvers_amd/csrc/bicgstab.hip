@@ -1,4 +1,4 @@
-// bicgstab.hip -- BiCGSTAB on one GPU.
+// bicgstab.hip -- BiCGSTAB (solver id 6) and CGNR (solver id 40) on one GPU.
 //
 // Stands in for HYPRE_ParCSRBiCGSTABSetup/Solve as the reference drives them for solver id 6
 // (solvers.c:517-564: PrintLevel, Logging, Tol, MaxIter, identity preconditioner).
@@ -351,6 +351,309 @@ int mk_bicgstab_destroy(mk_bicgstab *S) {
   if (!S) return MK_OK;
   if (ctx().ready) (void)hipStreamSynchronize(ctx().stream);
   bicg_release(S);
+  delete S;
+  return MK_OK;
+}
+
+}  // extern "C"
+
+// =============================================================================== CGNR
+// Stands in for HYPRE_ParCSRCGNRSetup/Solve as the reference drives them for solver id 40
+// (solvers.c:864-906: MaxIter, Tol, Logging, identity preconditioner): CG on A^T A x = A^T b following the
+// published hypre_CGNRSolve loop (oracle/oracle.c orc_cgnr lists the steps).  PARITY UNPINNED.
+// A^T is built once at setup by the device COO -> CSR conversion and analysed like any other matrix (the
+// transpose of a stencil is a stencil, so it gets the same kernel).  Per iteration: q = A p, t = A^T r, four
+// vector kernels, and the two conditional kernels that recompute r = b - A x when <r,r> passes the test.
+// Algorithmic bytes per iteration: 2 SpMV + 112 n.
+namespace mk {
+
+struct CgnrState {
+  double gamma, gamma_old, i_prod, bi_prod, eps;
+  long long iter;
+  int done;        // 0 running, 1 converged
+  int converged;
+  int skip_true;
+  int pad;
+};
+
+// partials of <b,b>, <r,r>
+static __global__ __launch_bounds__(kVecThreads) void cgnr_init_dots_kernel(int64_t n, const double *__restrict__ b, const double *__restrict__ r,
+                                                                            double *__restrict__ slab) {
+  double v[2] = {0.0, 0.0};
+  for (int64_t i = (int64_t)blockIdx.x * kVecThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kVecThreads) {
+    v[0] += b[i] * b[i];
+    v[1] += r[i] * r[i];
+  }
+  __shared__ double smem[2 * (kVecThreads / 64)];
+  block_sum<2, kVecThreads>(v, smem);
+  if (threadIdx.x == 0) {
+    slab[blockIdx.x] = v[0];
+    slab[kSlabStride + blockIdx.x] = v[1];
+  }
+}
+
+// p = t, partial of <t,t>
+static __global__ __launch_bounds__(kVecThreads) void cgnr_init_p_kernel(int64_t n, const double *__restrict__ t, double *__restrict__ p,
+                                                                         double *__restrict__ slab) {
+  double v[1] = {0.0};
+  for (int64_t i = (int64_t)blockIdx.x * kVecThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kVecThreads) {
+    const double ti = t[i];
+    p[i] = ti;
+    v[0] += ti * ti;
+  }
+  __shared__ double smem[kVecThreads / 64];
+  block_sum<1, kVecThreads>(v, smem);
+  if (threadIdx.x == 0) slab[blockIdx.x] = v[0];
+}
+
+static __global__ __launch_bounds__(kVecThreads) void cgnr_init_scalars_kernel(const double *slab_bb_rr, const double *slab_tt, int nblocks,
+                                                                               double tol, CgnrState *st, double *norms) {
+  __shared__ double smem[2 * (kVecThreads / 64)];
+  double v[2], g[1];
+  reduce_slab<2, kVecThreads>(slab_bb_rr, nblocks, kSlabStride, v, smem);
+  reduce_slab<1, kVecThreads>(slab_tt, nblocks, kSlabStride, g, smem);
+  if (threadIdx.x == 0) {
+    CgnrState s;
+    memset(&s, 0, sizeof(s));
+    s.bi_prod = v[0];
+    s.i_prod = v[1];
+    s.eps = tol * tol * v[0];
+    s.gamma = g[0];
+    s.skip_true = 1;
+    *st = s;
+    if (norms) norms[0] = sqrt(v[1] / v[0]);
+  }
+}
+
+// alpha = gamma / <q,q>;  x += alpha p;  r -= alpha q;  partial of <r,r>
+static __global__ __launch_bounds__(kVecThreads) void cgnr_step1_kernel(int64_t n, const double *__restrict__ p, const double *__restrict__ q,
+                                                                        double *__restrict__ x, double *__restrict__ r,
+                                                                        const double *__restrict__ slab_in, int nblocks_in,
+                                                                        double *__restrict__ slab_out, CgnrState *st) {
+  if (st->done != 0) return;
+  __shared__ double smem[kVecThreads / 64];
+  double d[1];
+  reduce_slab<1, kVecThreads>(slab_in, nblocks_in, kSlabStride, d, smem);
+  const double alpha = st->gamma / d[0];
+  double v[1] = {0.0};
+  for (int64_t i = (int64_t)blockIdx.x * kVecThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kVecThreads) {
+    x[i] += alpha * p[i];
+    double ri = r[i];
+    ri -= alpha * q[i];
+    r[i] = ri;
+    v[0] += ri * ri;
+  }
+  block_sum<1, kVecThreads>(v, smem);
+  if (threadIdx.x == 0) slab_out[blockIdx.x] = v[0];
+  if (blockIdx.x == 0 && threadIdx.x == 0) st->iter += 1;
+}
+
+// slab_rr: <r,r> of the recursive residual; slab_tt: <t,t>.  Logs the norm, raises the candidate flag
+static __global__ __launch_bounds__(kVecThreads) void cgnr_norm_kernel(const double *slab_rr, const double *slab_tt, int nblocks, CgnrState *st,
+                                                                       double *norms) {
+  if (st->done != 0) return;
+  __shared__ double smem[kVecThreads / 64];
+  double v[1], g[1];
+  reduce_slab<1, kVecThreads>(slab_rr, nblocks, kSlabStride, v, smem);
+  reduce_slab<1, kVecThreads>(slab_tt, nblocks, kSlabStride, g, smem);
+  if (threadIdx.x == 0) {
+    st->i_prod = v[0];
+    st->gamma_old = st->gamma;
+    st->gamma = g[0];
+    if (norms) norms[st->iter] = sqrt(v[0] / st->bi_prod);
+    st->skip_true = (v[0] < st->eps) ? 0 : 1;
+  }
+}
+
+// slab_in: <r,r> of r as it stands now (b - A x if it was a candidate).  beta = gamma/gamma_old; p = beta p + t
+static __global__ __launch_bounds__(kVecThreads) void cgnr_step2_kernel(int64_t n, const double *__restrict__ t, double *__restrict__ p,
+                                                                        const double *__restrict__ slab_in, int nblocks_in, CgnrState *st) {
+  if (st->done != 0) return;
+  __shared__ double smem[kVecThreads / 64];
+  const bool leader = (blockIdx.x == 0 && threadIdx.x == 0);
+  const bool cand = (st->skip_true == 0);
+  const double gamma = st->gamma, gamma_old = st->gamma_old, eps = st->eps;
+  if (cand) {
+    double d[1];
+    reduce_slab<1, kVecThreads>(slab_in, nblocks_in, kSlabStride, d, smem);
+    if (leader) st->i_prod = d[0];
+    if (d[0] < eps) {
+      if (leader) { st->converged = 1; st->done = 1; st->skip_true = 1; }
+      return;
+    }
+  }
+  const double beta = gamma / gamma_old;
+  for (int64_t i = (int64_t)blockIdx.x * kVecThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kVecThreads)
+    p[i] = __dadd_rn(__dmul_rn(beta, p[i]), t[i]);   // hypre scales p, then adds t: two roundings
+}
+
+}  // namespace mk
+
+struct mk_cgnr {
+  int max_iter = 1000;   // solvers.c:83
+  double tol = 1e-6;     // solvers.c:84
+  int logging = 0, check_every = 16;
+  int64_t n = 0;
+  mk_matrix *AT = nullptr;
+  double *r = nullptr, *p = nullptr, *q = nullptr, *t = nullptr;
+  double *slab1 = nullptr, *slab2 = nullptr, *slab3 = nullptr;
+  mk::CgnrState *state = nullptr;
+  double *norms = nullptr;
+  int norms_cap = 0;
+  long long iterations = 0;
+  double rel_res_norm = 0.0;
+  int converged = 0;
+};
+
+static void cgnr_release(mk_cgnr *S) {
+  if (S->AT) { mk_matrix_destroy(S->AT); S->AT = nullptr; }
+  dev_free(S->r); dev_free(S->p); dev_free(S->q); dev_free(S->t);
+  dev_free(S->slab1); dev_free(S->slab2); dev_free(S->slab3); dev_free(S->state); dev_free(S->norms);
+  S->r = S->p = S->q = S->t = S->slab1 = S->slab2 = S->slab3 = S->norms = nullptr;
+  S->state = nullptr;
+  S->n = 0;
+}
+
+extern "C" {
+
+int mk_cgnr_create(mk_cgnr **solver) {
+  MK_REQUIRE_INIT();
+  if (!solver) return fail(MK_ERR_INVALID, "mk_cgnr_create: null argument");
+  *solver = new mk_cgnr();
+  return MK_OK;
+}
+
+#define MK_CGNR_SETTER(name, field, type, cond)                                       \
+  int name(mk_cgnr *solver, type v) {                                                  \
+    if (!solver) return fail(MK_ERR_INVALID, #name ": null solver");                   \
+    if (!(cond)) return fail(MK_ERR_INVALID, #name ": value out of range");            \
+    solver->field = v;                                                                 \
+    return MK_OK;                                                                      \
+  }
+MK_CGNR_SETTER(mk_cgnr_set_max_iter, max_iter, int, v >= 0)
+MK_CGNR_SETTER(mk_cgnr_set_tol, tol, double, v >= 0.0)
+MK_CGNR_SETTER(mk_cgnr_set_logging, logging, int, v >= 0)
+MK_CGNR_SETTER(mk_cgnr_set_check_every, check_every, int, v >= 1)
+#undef MK_CGNR_SETTER
+
+int mk_cgnr_setup(mk_cgnr *S, const mk_matrix *A, const mk_vector *b, const mk_vector *x) {
+  MK_REQUIRE_INIT();
+  if (!S || !A || !b || !x) return fail(MK_ERR_INVALID, "mk_cgnr_setup: null argument");
+  if (A->nrows != A->ncols) return fail(MK_ERR_INVALID, "mk_cgnr_setup: matrix is %lld x %lld, must be square", (long long)A->nrows, (long long)A->ncols);
+  if (b->n != A->nrows || x->n != A->nrows) return fail(MK_ERR_INVALID, "mk_cgnr_setup: vector length does not match the matrix");
+  cgnr_release(S);
+  S->n = A->nrows;
+  MK_TRY(build_transpose(A, &S->AT));
+  MK_TRY(dev_alloc(&S->r, (size_t)S->n));
+  MK_TRY(dev_alloc(&S->p, (size_t)S->n));
+  MK_TRY(dev_alloc(&S->q, (size_t)S->n));
+  MK_TRY(dev_alloc(&S->t, (size_t)S->n));
+  MK_TRY(dev_alloc(&S->slab1, (size_t)2 * kSlabStride));
+  MK_TRY(dev_alloc(&S->slab2, (size_t)2 * kSlabStride));
+  MK_TRY(dev_alloc(&S->slab3, (size_t)2 * kSlabStride));
+  MK_TRY(dev_alloc(&S->state, 1));
+  if (S->logging > 0) {
+    S->norms_cap = S->max_iter + 1;
+    MK_TRY(dev_alloc(&S->norms, (size_t)S->norms_cap));
+  }
+  MK_TRY(analyse_matrix(const_cast<mk_matrix *>(A)));
+  MK_TRY(analyse_matrix(S->AT));
+  MK_HIP(hipStreamSynchronize(ctx().stream));
+  return MK_OK;
+}
+
+int mk_cgnr_solve(mk_cgnr *S, const mk_matrix *A, const mk_vector *b, mk_vector *x) {
+  MK_REQUIRE_INIT();
+  if (!S || !A || !b || !x) return fail(MK_ERR_INVALID, "mk_cgnr_solve: null argument");
+  if (S->n != A->nrows || !S->state || !S->AT) return fail(MK_ERR_INVALID, "mk_cgnr_solve: call mk_cgnr_setup with this matrix first");
+  if (b->n != S->n || x->n != S->n) return fail(MK_ERR_INVALID, "mk_cgnr_solve: vector length does not match the matrix");
+  if (S->norms && S->norms_cap < S->max_iter + 1) return fail(MK_ERR_INVALID, "mk_cgnr_solve: max_iter was raised after setup");
+  Context &c = ctx();
+  const int64_t n = S->n;
+  S->iterations = 0; S->rel_res_norm = 0.0; S->converged = 0;
+  if (n == 0) return MK_OK;
+  const int vb = vec_blocks(n);
+  const dim3 grid(vb), block(kVecThreads);
+  CgnrState *hst = static_cast<CgnrState *>(c.pinned);
+
+  // r = b - A x;  t = A^T r;  p = t;  gamma = <t,t>
+  hipLaunchKernelGGL(copy_kernel, grid, dim3(256), 0, c.stream, S->r, b->d, n);
+  MK_TRY(launch_spmv(A, -1.0, x->d, 1.0, S->r));
+  hipLaunchKernelGGL(cgnr_init_dots_kernel, grid, block, 0, c.stream, n, b->d, S->r, S->slab1);
+  MK_TRY(launch_spmv(S->AT, 1.0, S->r, 0.0, S->t));
+  hipLaunchKernelGGL(cgnr_init_p_kernel, grid, block, 0, c.stream, n, S->t, S->p, S->slab2);
+  hipLaunchKernelGGL(cgnr_init_scalars_kernel, dim3(1), block, 0, c.stream, S->slab1, S->slab2, vb, S->tol, S->state, S->norms);
+  MK_HIP(hipMemcpyAsync(&hst[0], S->state, sizeof(CgnrState), hipMemcpyDeviceToHost, c.stream));
+  MK_HIP(hipStreamSynchronize(c.stream));
+  if (hst[0].bi_prod == 0.0) {   // hypre: zero right-hand side -> x = b, no iterations
+    hipLaunchKernelGGL(copy_kernel, grid, dim3(256), 0, c.stream, x->d, b->d, n);
+    MK_HIP(hipStreamSynchronize(c.stream));
+    return MK_OK;
+  }
+
+  bool stop = false;
+  for (int it = 0; it < S->max_iter && !stop; it++) {
+    int *done = &S->state->done, *skip = &S->state->skip_true;
+    MK_TRY(launch_spmv(A, 1.0, S->p, 0.0, S->q, done));
+    hipLaunchKernelGGL(dot2_kernel, grid, block, 0, c.stream, n, S->q, S->q, nullptr, nullptr, S->slab1, done);
+    hipLaunchKernelGGL(cgnr_step1_kernel, grid, block, 0, c.stream, n, S->p, S->q, x->d, S->r, S->slab1, vb, S->slab2, S->state);
+    MK_TRY(launch_spmv(S->AT, 1.0, S->r, 0.0, S->t, done));
+    hipLaunchKernelGGL(dot2_kernel, grid, block, 0, c.stream, n, S->t, S->t, nullptr, nullptr, S->slab3, done);
+    hipLaunchKernelGGL(cgnr_norm_kernel, dim3(1), block, 0, c.stream, S->slab2, S->slab3, vb, S->state, S->norms);
+    // only when <r,r> passed: r = b - A x, and its norm
+    hipLaunchKernelGGL(copy_unless_kernel, grid, dim3(256), 0, c.stream, S->r, b->d, n, skip);
+    MK_TRY(launch_spmv(A, -1.0, x->d, 1.0, S->r, skip));
+    hipLaunchKernelGGL(dot2_kernel, grid, block, 0, c.stream, n, S->r, S->r, nullptr, nullptr, S->slab1, skip);
+    hipLaunchKernelGGL(cgnr_step2_kernel, grid, block, 0, c.stream, n, S->t, S->p, S->slab1, vb, S->state);
+    if ((it + 1) % S->check_every == 0) {
+      MK_HIP(hipMemcpyAsync(&hst[0], S->state, sizeof(CgnrState), hipMemcpyDeviceToHost, c.stream));
+      MK_HIP(hipStreamSynchronize(c.stream));
+      if (hst[0].done != 0) stop = true;
+    }
+  }
+  MK_HIP(hipGetLastError());
+  MK_HIP(hipMemcpyAsync(&hst[0], S->state, sizeof(CgnrState), hipMemcpyDeviceToHost, c.stream));
+  MK_HIP(hipStreamSynchronize(c.stream));
+  S->iterations = hst[0].iter;
+  S->converged = hst[0].converged;
+  S->rel_res_norm = hst[0].bi_prod > 0.0 ? sqrt(hst[0].i_prod / hst[0].bi_prod) : 0.0;
+  return MK_OK;
+}
+
+int mk_cgnr_get_num_iterations(const mk_cgnr *S, long long *iterations) {
+  if (!S || !iterations) return fail(MK_ERR_INVALID, "mk_cgnr_get_num_iterations: null argument");
+  *iterations = S->iterations;
+  return MK_OK;
+}
+
+int mk_cgnr_get_final_relative_residual_norm(const mk_cgnr *S, double *norm) {
+  if (!S || !norm) return fail(MK_ERR_INVALID, "mk_cgnr_get_final_relative_residual_norm: null argument");
+  *norm = S->rel_res_norm;
+  return MK_OK;
+}
+
+int mk_cgnr_get_converged(const mk_cgnr *S, int *converged) {
+  if (!S || !converged) return fail(MK_ERR_INVALID, "mk_cgnr_get_converged: null argument");
+  *converged = S->converged;
+  return MK_OK;
+}
+
+int mk_cgnr_get_residual_history(const mk_cgnr *S, double *norms, int capacity) {
+  MK_REQUIRE_INIT();
+  if (!S || !norms || capacity < 0) return fail(MK_ERR_INVALID, "mk_cgnr_get_residual_history: bad argument");
+  if (!S->norms) return fail(MK_ERR_INVALID, "mk_cgnr_get_residual_history: logging was off at setup");
+  const int count = (int)std::min<long long>(S->iterations + 1, capacity);
+  if (count > 0) {
+    MK_HIP(hipMemcpyAsync(norms, S->norms, sizeof(double) * count, hipMemcpyDeviceToHost, ctx().stream));
+    MK_HIP(hipStreamSynchronize(ctx().stream));
+  }
+  return count;
+}
+
+int mk_cgnr_destroy(mk_cgnr *S) {
+  if (!S) return MK_OK;
+  if (ctx().ready) (void)hipStreamSynchronize(ctx().stream);
+  cgnr_release(S);
   delete S;
   return MK_OK;
 }

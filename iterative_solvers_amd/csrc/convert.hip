@@ -577,3 +577,37 @@ int mk_sort_coo_row(const SparseMatrixCOO *coo, SparseMatrixCOO *sorted) {
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------ transpose
+namespace mk {
+
+static __global__ void expand_rows_kernel(int64_t nrows, const int *__restrict__ rowptr, int *__restrict__ rows) {
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += (int64_t)gridDim.x * blockDim.x)
+    for (int k = rowptr[r]; k < rowptr[r + 1]; k++) rows[k] = (int)r;
+}
+
+// A^T as a matrix of its own (CGNR needs A^T r every iteration): entries as (col, row, val) through the same
+// stable radix sort as any other COO, so rows of A^T hold their entries by ascending row of A
+int build_transpose(const mk_matrix *A, mk_matrix **out) {
+  Context &c = ctx();
+  mk_coo d;
+  d.nrows = A->ncols; d.ncols = A->nrows; d.nnz = A->nnz;
+  int rc = dev_alloc(&d.rows, (size_t)A->nnz);
+  if (rc == MK_OK) rc = dev_alloc(&d.cols, (size_t)A->nnz);
+  if (rc == MK_OK) rc = dev_alloc(&d.vals, (size_t)A->nnz);
+  if (rc != MK_OK) { dev_free(d.rows); dev_free(d.cols); dev_free(d.vals); return rc; }
+  if (A->nnz > 0) {
+    (void)hipMemcpyAsync(d.rows, A->col, sizeof(int) * (size_t)A->nnz, hipMemcpyDeviceToDevice, c.stream);
+    (void)hipMemcpyAsync(d.vals, A->val, sizeof(double) * (size_t)A->nnz, hipMemcpyDeviceToDevice, c.stream);
+    const int blocks = (int)std::min<int64_t>((A->nrows + 255) / 256, 4096);
+    hipLaunchKernelGGL(expand_rows_kernel, dim3(std::max(blocks, 1)), dim3(256), 0, c.stream, A->nrows, A->rowptr, d.cols);
+  }
+  mk_matrix *M = new mk_matrix();
+  rc = device_coo_to_csr(&d, M, nullptr);
+  dev_free(d.rows); dev_free(d.cols); dev_free(d.vals);
+  if (rc != MK_OK) { mk_matrix_destroy(M); return rc; }
+  *out = M;
+  return MK_OK;
+}
+
+}  // namespace mk

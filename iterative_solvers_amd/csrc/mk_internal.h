@@ -189,6 +189,7 @@ int exclusive_scan_u32(const uint32_t *in, uint32_t *out, size_t n, uint32_t *to
 // (they are freed or become the CSR arrays).  sorted_rows_out (optional) receives the
 // sorted row keys (device buffer of nnz ints owned by caller afterwards).
 int device_coo_to_csr(mk_coo *coo, mk_matrix *A, int **sorted_rows_out);
+int build_transpose(const mk_matrix *A, mk_matrix **out);   // A^T through the same conversion (cgnr.hip)
 
 }  // namespace mk
 

@@ -518,3 +518,72 @@ done:
   info->rel_res_norm = b_norm > 0.0 ? r_norm / b_norm : r_norm;
   free(r0); free(r); free(p); free(q); free(sv);
 }
+
+/* ---- CGNR (solver id 40, solvers.c:864-906: MaxIter, Tol, Logging, identity preconditioner) ----
+ * CG on the normal equations A^T A x = A^T b, restating the published hypre_CGNRSolve loop:
+ *   eps = tol^2 <b,b>;  r = b - A x;  t = A^T r;  p = t;  gamma = <t,t>
+ *   loop: q = A p; alpha = gamma/<q,q>; x += alpha p; r -= alpha q; t = A^T r; gamma' = <t,t>;
+ *         <r,r> < eps ? recompute r = b - A x, stop if still < eps;
+ *         beta = gamma'/gamma; p = t + beta p (scale p, then add t).
+ *   rel_res_norm = sqrt(<r,r>/<b,b>).  Zero right-hand side: x = b, no iterations.
+ * PARITY UNPINNED. */
+void orc_cgnr(uint32_t n, const int *rowptr, const int *col, const double *val, const double *b,
+              double *x, double tol, int maxit, int use_omp, orc_solve_info *info, double *rel_norms) {
+  /* A^T as CSR (counting sort by column, stable) */
+  const int nnz = rowptr[n];
+  int *trp = (int *)calloc((size_t)n + 1, sizeof(int)), *tci = (int *)malloc(sizeof(int) * (size_t)(nnz > 0 ? nnz : 1));
+  double *tv = (double *)malloc(sizeof(double) * (size_t)(nnz > 0 ? nnz : 1));
+  for (int k = 0; k < nnz; k++) trp[col[k] + 1]++;
+  for (uint32_t i = 0; i < n; i++) trp[i + 1] += trp[i];
+  int *cur = (int *)malloc(sizeof(int) * ((size_t)n + 1));
+  memcpy(cur, trp, sizeof(int) * ((size_t)n + 1));
+  for (uint32_t i = 0; i < n; i++)
+    for (int k = rowptr[i]; k < rowptr[i + 1]; k++) { const int d = cur[col[k]]++; tci[d] = (int)i; tv[d] = val[k]; }
+  free(cur);
+  double *r = (double *)malloc(sizeof(double) * n), *p = (double *)malloc(sizeof(double) * n);
+  double *q = (double *)malloc(sizeof(double) * n), *t = (double *)malloc(sizeof(double) * n);
+  info->iterations = 0; info->converged = 0; info->breakdown = 0; info->rel_res_norm = 0.0;
+  const double bi_prod = v_dot(n, b, b, use_omp);
+  const double eps = tol * tol * bi_prod;
+  long long i = 0;
+  double i_prod = 0.0;
+  if (bi_prod == 0.0) {
+    memcpy(x, b, sizeof(double) * n);
+    if (rel_norms) rel_norms[0] = 0.0;
+    goto done;
+  }
+  memcpy(r, b, sizeof(double) * n);
+  spmv(n, rowptr, col, val, -1.0, x, 1.0, r, use_omp);
+  i_prod = v_dot(n, r, r, use_omp);
+  if (rel_norms) rel_norms[0] = sqrt(i_prod / bi_prod);
+  spmv(n, trp, tci, tv, 1.0, r, 0.0, t, use_omp);
+  memcpy(p, t, sizeof(double) * n);
+  double gamma = v_dot(n, t, t, use_omp);
+  while (i + 1 <= maxit) {
+    i++;
+    spmv(n, rowptr, col, val, 1.0, p, 0.0, q, use_omp);
+    const double alpha = gamma / v_dot(n, q, q, use_omp);
+    const double gamma_old = gamma;
+    v_axpy(n, alpha, p, x, use_omp);
+    v_axpy(n, -alpha, q, r, use_omp);
+    spmv(n, trp, tci, tv, 1.0, r, 0.0, t, use_omp);
+    gamma = v_dot(n, t, t, use_omp);
+    i_prod = v_dot(n, r, r, use_omp);
+    if (rel_norms) rel_norms[i] = sqrt(i_prod / bi_prod);
+    if (i_prod < eps) {
+      memcpy(r, b, sizeof(double) * n);
+      spmv(n, rowptr, col, val, -1.0, x, 1.0, r, use_omp);
+      i_prod = v_dot(n, r, r, use_omp);
+      if (i_prod < eps) { info->converged = 1; break; }
+    }
+    const double beta = gamma / gamma_old;
+    for (uint32_t k = 0; k < n; k++) {
+      const double sp = beta * p[k];
+      p[k] = sp + t[k];
+    }
+  }
+done:
+  info->iterations = i;
+  info->rel_res_norm = bi_prod > 0.0 ? sqrt(i_prod / bi_prod) : 0.0;
+  free(trp); free(tci); free(tv); free(r); free(p); free(q); free(t);
+}

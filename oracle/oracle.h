@@ -81,6 +81,11 @@ void orc_jacobi(uint32_t n, const int *rowptr, const int *col, const double *val
 void orc_bicgstab(uint32_t n, const int *rowptr, const int *col, const double *val, const double *b,
                   double *x, double tol, int maxit, int use_omp, orc_solve_info *info, double *norms);
 
+/* CGNR as solvers.c:864-906 drives it (solver id 40: maxit, tol, identity preconditioner).  rel_norms may be
+ * NULL or hold maxit+1 doubles (||r||/||b||). */
+void orc_cgnr(uint32_t n, const int *rowptr, const int *col, const double *val, const double *b,
+              double *x, double tol, int maxit, int use_omp, orc_solve_info *info, double *rel_norms);
+
 /* ---- synthetic matrices (bench.py / tests; same definitions as the device generators) */
 uint64_t orc_splitmix64(uint64_t x);
 /* R-MAT edge i of a 2^scale graph: row/col bits drawn from counter-based splitmix64 */

@@ -618,6 +618,61 @@ def _dense(rp, ci, v, n):
     return M
 
 
+# ------------------------------------------------------------------ CGNR (solver id 40)
+@pytest.mark.parametrize("kind,dims,kernel", [(5, (40, 32, 1), None), (7, (14, 12, 10), None), (7, (32, 16, 8), "sweep")])
+def test_cgnr_matches_oracle(kind, dims, kernel):
+    rp, ci, v, n = _convection_diffusion(kind, dims)
+    bh = np.random.default_rng(12).normal(size=n)
+    tol = 1e-8
+    o = oracle.cgnr(rp, ci, v, bh, tol=tol, maxit=5000, want_norms=True)
+    A = mk.Matrix.from_csr(n, n, rp, ci, v)
+    if kernel == "sweep":
+        A.set_spmv_kernel(mk.SPMV_SWEEP)
+    for check_every in (1, 16):
+        b, x = mk.Vector(n, values=bh), mk.Vector(n, fill=0.0)
+        S = mk.CGNR(max_iter=5000, tol=tol, logging=1, check_every=check_every)
+        S.setup(A, b, x)
+        res = S.solve(A, b, x)
+        assert res["converged"] == 1 == o["converged"]
+        assert abs(res["iterations"] - o["iterations"]) <= max(CG_ITER_TOL, 0.02 * o["iterations"]), (res, o["iterations"])
+        xs = x.get()
+        true_rel = np.linalg.norm(bh - oracle.csr_spmv(rp, ci, v, xs)) / np.linalg.norm(bh)
+        assert true_rel < tol and abs(res["rel_res_norm"] - true_rel) <= 1e-3 * tol
+        assert np.linalg.norm(xs - o["x"]) <= 1e-5 * np.linalg.norm(o["x"])
+        hist = S.residual_history(6000)
+        assert hist.size == res["iterations"] + 1
+        m = min(hist.size, o["rel_norms"].size, 30)
+        assert np.allclose(hist[:m], o["rel_norms"][:m], rtol=1e-8)
+
+
+def test_cgnr_transpose_maxit_and_zero_rhs():
+    # a matrix that is far from symmetric: the transpose built at setup must be the real one
+    rng = np.random.default_rng(13)
+    n = 3000
+    lens = rng.integers(1, 7, n)
+    rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    ci = rng.integers(0, n, rp[-1]).astype(np.int32)
+    v = rng.normal(size=rp[-1])
+    rows = np.repeat(np.arange(n), lens)
+    # make it well conditioned: strong diagonal appended to every row
+    rp2 = rp + np.arange(n + 1, dtype=np.int32)
+    ci2 = np.insert(ci, rp[1:], np.arange(n)).astype(np.int32)
+    v2 = np.insert(v, rp[1:], 8.0 + rng.uniform(0, 1, n))
+    A = mk.Matrix.from_csr(n, n, rp2, ci2, v2)
+    bh = rng.normal(size=n)
+    b, x = mk.Vector(n, values=bh), mk.Vector(n, fill=0.0)
+    S = mk.CGNR(max_iter=6, tol=1e-14)
+    S.setup(A, b, x)
+    res = S.solve(A, b, x)
+    o = oracle.cgnr(rp2, ci2, v2, bh, tol=1e-14, maxit=6)
+    assert res["iterations"] == 6 and res["converged"] == 0
+    assert np.isclose(res["rel_res_norm"], o["rel_res_norm"], rtol=1e-9)
+    assert np.allclose(x.get(), o["x"], rtol=1e-9, atol=1e-13)
+    b0, x0 = mk.Vector(n, fill=0.0), mk.Vector(n, fill=2.0)
+    r0 = S.solve(A, b0, x0)
+    assert r0["iterations"] == 0 and np.all(x0.get() == 0.0)
+
+
 @pytest.mark.parametrize("check_every", [1, 5])
 def test_jacobi_banded_matches_oracle(check_every):
     # config 5 shape scaled down

@@ -226,6 +226,21 @@ def test_driver_power_sampling(tmp_path):
 
 
 @pytest.mark.gpu
+def test_driver_cgnr_output_lines(tmp_path):
+    # solver id 40 (solvers.c:864-906)
+    mtx = tmp_path / "poisson.mtx"
+    rp, ci, v = _write_poisson(mtx, 24, 20, shuffle_seed=4)
+    out = subprocess.run([os.path.join(HOST, "solver"), "-solver", "40", "-mtx", str(mtx), "-tol", "1e-8",
+                          "-maxit", "5000"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert re.search(r"^CGNR Solve time = [0-9.]+ seconds$", out.stdout, re.M)
+    it = int(re.search(r"^Iterations = (\d+)$", out.stdout, re.M).group(1))
+    nrm = float(re.search(r"^Final Relative Residual Norm = ([0-9.e+-]+)$", out.stdout, re.M).group(1))
+    o = oracle.cgnr(rp, ci, v, np.ones(rp.size - 1), tol=1e-8, maxit=5000)
+    assert abs(it - o["iterations"]) <= max(2, 0.02 * o["iterations"]) and nrm < 1e-8
+
+
+@pytest.mark.gpu
 def test_driver_binary_cache(tmp_path):
     mtx = tmp_path / "poisson.mtx"
     _write_poisson(mtx, 40, 40, shuffle_seed=2)
