@@ -4,6 +4,7 @@
  * reference calls HYPRE.  One process drives one MI355X.
  *
  *   -solver 6   BiCGSTAB, no preconditioner                                (solvers.c:517-564)
+ *   -solver 12  GMRES(30), no preconditioner                               (solvers.c:1183-1245)
  *   -solver 40  CGNR, no preconditioner                                    (solvers.c:864-906)
  *   -solver 50  PCG, no preconditioner, two-norm + rel_change stopping   (solvers.c:724-776)
  *   -solver 51  PCG with diagonal scaling      (extension)
@@ -48,6 +49,7 @@ static void usage(const char *argv0) {
   printf("  -dev <id>              : GPU to use (default 0)\n");
   printf("  -solver <ID>           : solver ID\n");
   printf("                           6  - BiCGSTAB\n");
+  printf("                           12 - GMRES(30)\n");
   printf("                           40 - CGNR\n");
   printf("                           50 - PCG\n");
   printf("                           51 - PCG + diagonal scaling\n");
@@ -86,9 +88,9 @@ int main(int argc, char *argv[]) {
     else i += 1;                                                      /* unknown flags are skipped (:149-151) */
   }
   if (!mtx) { usage(argv[0]); return 1; }
-  if (solver_id != 6 && solver_id != 40 && solver_id != 50 && solver_id != 51 && solver_id != 70) {
+  if (solver_id != 6 && solver_id != 12 && solver_id != 40 && solver_id != 50 && solver_id != 51 && solver_id != 70) {
     printf("Invalid solver id specified.\n");
-    fprintf(stderr, "solver %d is a HYPRE preconditioner/solver stack outside this library; use 6, 40, 50, 51 or 70\n", solver_id);
+    fprintf(stderr, "solver %d is a HYPRE preconditioner/solver stack outside this library; use 6, 12, 40, 50, 51 or 70\n", solver_id);
     return 1;
   }
 
@@ -211,6 +213,28 @@ int main(int argc, char *argv[]) {
     CK(mk_bicgstab_get_num_iterations(solver, &num_iterations));      /* :553 */
     CK(mk_bicgstab_get_final_relative_residual_norm(solver, &final_res_norm)); /* :554 */
     CK(mk_bicgstab_destroy(solver));                                  /* :563 */
+  } else if (solver_id == 12) {
+    mk_gmres *solver = NULL;
+    double ts = -now_s();                                             /* :1187 */
+    CK(mk_gmres_create(&solver));                                     /* :1189 */
+    CK(mk_gmres_set_max_iter(solver, maxit));                         /* :1191 */
+    CK(mk_gmres_set_k_dim(solver, 30));                               /* :1192, restart = 30 (:460) */
+    CK(mk_gmres_set_tol(solver, tol));                                /* :1193 */
+    CK(mk_gmres_set_print_level(solver, prnt_info));                  /* :1195 */
+    CK(mk_gmres_set_logging(solver, 1));                              /* :1196 */
+    CK(mk_gmres_setup(solver, A, b, x));                              /* :1200 */
+    CK(mk_synchronize());
+    ts += now_s();
+    printf("\nGMRES Setup time = %f seconds\n\n", ts);               /* :1206 */
+    double t = -now_s();                                              /* :1213 */
+    for (int i = 0; i < niter; i++) CK(mk_gmres_solve(solver, A, b, x)); /* :1216-1217 */
+    CK(mk_synchronize());
+    t += now_s();
+    walltime = t;
+    printf("\nGMRES Solve time = %f seconds\n\n", walltime);         /* :1227 */
+    CK(mk_gmres_get_num_iterations(solver, &num_iterations));         /* :1231 */
+    CK(mk_gmres_get_final_relative_residual_norm(solver, &final_res_norm)); /* :1232 */
+    CK(mk_gmres_destroy(solver));
   } else if (solver_id == 40) {
     mk_cgnr *solver = NULL;
     CK(mk_cgnr_create(&solver));                                      /* :869 */

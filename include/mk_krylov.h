@@ -67,6 +67,7 @@ typedef struct mk_coo mk_coo;         /* a COO matrix resident in device memory 
 typedef struct mk_pcg mk_pcg;         /* HYPRE_Solver for PCG (solvers.c:65,729) */
 typedef struct mk_bicgstab mk_bicgstab;   /* HYPRE_Solver for BiCGSTAB (solvers.c:65,524) */
 typedef struct mk_cgnr mk_cgnr;           /* HYPRE_Solver for CGNR (solvers.c:65,869) */
+typedef struct mk_gmres mk_gmres;         /* HYPRE_Solver for GMRES (solvers.c:65,1189) */
 typedef struct mk_jacobi mk_jacobi;   /* extension: plain Jacobi iteration (no reference counterpart) */
 
 /* ---- life cycle: HYPRE_Init() / HYPRE_Finalize() (solvers.c:79,1560) ------------------- */
@@ -215,6 +216,25 @@ int mk_cgnr_get_converged(const mk_cgnr *solver, int *converged);
 /* ||r|| / ||b|| after each iteration (needs logging > 0 at setup); returns the number of entries written */
 int mk_cgnr_get_residual_history(const mk_cgnr *solver, double *norms, int capacity);
 int mk_cgnr_destroy(mk_cgnr *solver);
+
+/* ---- restarted GMRES, solver id 12 (solvers.c:1183-1245), identity preconditioner -----------
+ * HYPRE_ParCSRGMRESCreate :1189, SetMaxIter :1191, SetKDim :1192 (restart = 30, :460), SetTol :1193, SetPrintLevel :1195,
+ * SetLogging :1196, Setup :1200, Solve :1217, HYPRE_GMRESGetNumIterations :1231, GetFinalRelativeResidualNorm :1232.
+ * k_dim <= 62.  Stops when the residual estimate and then the recomputed residual b - A x are <= tol * ||b||. */
+int mk_gmres_create(mk_gmres **solver);
+int mk_gmres_set_max_iter(mk_gmres *solver, int max_iter);
+int mk_gmres_set_k_dim(mk_gmres *solver, int k_dim);
+int mk_gmres_set_tol(mk_gmres *solver, double tol);
+int mk_gmres_set_print_level(mk_gmres *solver, int level);
+int mk_gmres_set_logging(mk_gmres *solver, int logging);
+int mk_gmres_setup(mk_gmres *solver, const mk_matrix *A, const mk_vector *b, const mk_vector *x);
+int mk_gmres_solve(mk_gmres *solver, const mk_matrix *A, const mk_vector *b, mk_vector *x);
+int mk_gmres_get_num_iterations(const mk_gmres *solver, long long *iterations);
+int mk_gmres_get_final_relative_residual_norm(const mk_gmres *solver, double *norm);
+int mk_gmres_get_converged(const mk_gmres *solver, int *converged);
+/* absolute residual estimate after each iteration (needs logging > 0); returns the number of entries written */
+int mk_gmres_get_residual_history(const mk_gmres *solver, double *norms, int capacity);
+int mk_gmres_destroy(mk_gmres *solver);
 
 /* ---- plain Jacobi iteration, extension solver id 70 --------------- */
 int mk_jacobi_create(mk_jacobi **solver);

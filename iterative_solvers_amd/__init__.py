@@ -63,6 +63,10 @@ EXPORTS = [
     "mk_cgnr_create", "mk_cgnr_set_max_iter", "mk_cgnr_set_tol", "mk_cgnr_set_logging", "mk_cgnr_set_check_every",
     "mk_cgnr_setup", "mk_cgnr_solve", "mk_cgnr_get_num_iterations", "mk_cgnr_get_final_relative_residual_norm",
     "mk_cgnr_get_converged", "mk_cgnr_get_residual_history", "mk_cgnr_destroy",
+    "mk_gmres_create", "mk_gmres_set_max_iter", "mk_gmres_set_k_dim", "mk_gmres_set_tol", "mk_gmres_set_print_level",
+    "mk_gmres_set_logging", "mk_gmres_setup", "mk_gmres_solve", "mk_gmres_get_num_iterations",
+    "mk_gmres_get_final_relative_residual_norm", "mk_gmres_get_converged", "mk_gmres_get_residual_history",
+    "mk_gmres_destroy",
     "mk_jacobi_create", "mk_jacobi_set_max_iter", "mk_jacobi_set_tol", "mk_jacobi_set_check_every",
     "mk_jacobi_setup", "mk_jacobi_solve", "mk_jacobi_get_num_iterations",
     "mk_jacobi_get_final_relative_residual_norm", "mk_jacobi_get_converged", "mk_jacobi_destroy",
@@ -134,6 +138,13 @@ def load():
         "mk_cgnr_get_final_relative_residual_norm": [P, C.POINTER(C.c_double)],
         "mk_cgnr_get_converged": [P, C.POINTER(C.c_int)],
         "mk_cgnr_get_residual_history": [P, P, C.c_int], "mk_cgnr_destroy": [P],
+        "mk_gmres_create": [C.POINTER(P)], "mk_gmres_set_max_iter": [P, C.c_int], "mk_gmres_set_k_dim": [P, C.c_int],
+        "mk_gmres_set_tol": [P, C.c_double], "mk_gmres_set_print_level": [P, C.c_int], "mk_gmres_set_logging": [P, C.c_int],
+        "mk_gmres_setup": [P, P, P, P], "mk_gmres_solve": [P, P, P, P],
+        "mk_gmres_get_num_iterations": [P, C.POINTER(C.c_longlong)],
+        "mk_gmres_get_final_relative_residual_norm": [P, C.POINTER(C.c_double)],
+        "mk_gmres_get_converged": [P, C.POINTER(C.c_int)],
+        "mk_gmres_get_residual_history": [P, P, C.c_int], "mk_gmres_destroy": [P],
         "mk_jacobi_create": [C.POINTER(P)], "mk_jacobi_set_max_iter": [P, C.c_int],
         "mk_jacobi_set_tol": [P, C.c_double], "mk_jacobi_set_check_every": [P, C.c_int],
         "mk_jacobi_setup": [P, P, P, P], "mk_jacobi_solve": [P, P, P, P],
@@ -484,6 +495,43 @@ class CGNR:
     def __del__(self):
         if getattr(self, "h", None) and _lib is not None:
             _lib.mk_cgnr_destroy(self.h)
+            self.h = None
+
+
+class GMRES:
+    """HYPRE_ParCSRGMRES* life cycle as solvers.c:1183-1245 drives it (solver id 12, restart 30)"""
+
+    def __init__(self, max_iter=1000, tol=1e-6, k_dim=30, logging=1, print_level=0):
+        init()
+        self.h = C.c_void_p()
+        L = load()
+        _ck(L.mk_gmres_create(C.byref(self.h)))
+        _ck(L.mk_gmres_set_max_iter(self.h, max_iter))
+        _ck(L.mk_gmres_set_k_dim(self.h, k_dim))
+        _ck(L.mk_gmres_set_tol(self.h, tol))
+        _ck(L.mk_gmres_set_print_level(self.h, print_level))
+        _ck(L.mk_gmres_set_logging(self.h, logging))
+
+    def setup(self, A, b, x):
+        _ck(load().mk_gmres_setup(self.h, A.h, b.h, x.h))
+
+    def solve(self, A, b, x):
+        L = load()
+        _ck(L.mk_gmres_solve(self.h, A.h, b.h, x.h))
+        it, nrm, cv = C.c_longlong(), C.c_double(), C.c_int()
+        _ck(L.mk_gmres_get_num_iterations(self.h, C.byref(it)))
+        _ck(L.mk_gmres_get_final_relative_residual_norm(self.h, C.byref(nrm)))
+        _ck(L.mk_gmres_get_converged(self.h, C.byref(cv)))
+        return dict(iterations=it.value, rel_res_norm=nrm.value, converged=cv.value)
+
+    def residual_history(self, capacity):
+        out = np.empty(capacity)
+        n = _ck(load().mk_gmres_get_residual_history(self.h, out.ctypes.data, capacity))
+        return out[:n]
+
+    def __del__(self):
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.mk_gmres_destroy(self.h)
             self.h = None
 
 

@@ -54,6 +54,8 @@ def lib():
         L.orc_bicgstab.argtypes = [C.c_uint32, _i32p, _i32p, _f64p, _f64p, _f64p, C.c_double, C.c_int, C.c_int,
                                    C.POINTER(SolveInfo), C.c_void_p]
         L.orc_cgnr.argtypes = L.orc_bicgstab.argtypes
+        L.orc_gmres.argtypes = [C.c_uint32, _i32p, _i32p, _f64p, _f64p, _f64p, C.c_double, C.c_int, C.c_int, C.c_int,
+                                C.POINTER(SolveInfo), C.c_void_p]
         L.orc_splitmix64.argtypes = [C.c_uint64]
         L.orc_splitmix64.restype = C.c_uint64
         L.orc_rmat_coo.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_double, C.c_double, C.c_double,
@@ -160,6 +162,20 @@ def cgnr(rowptr, col, val, b, x0=None, tol=1e-6, maxit=1000, omp=False, want_nor
     out = dict(x=x, iterations=info.iterations, rel_res_norm=info.rel_res_norm, converged=info.converged)
     if want_norms:
         out["rel_norms"] = norms[: info.iterations + 1]
+    return out
+
+
+def gmres(rowptr, col, val, b, x0=None, tol=1e-6, maxit=1000, k_dim=30, omp=False, want_norms=False):
+    rowptr, col, val, b = _c(rowptr, np.int32), _c(col, np.int32), _c(val, np.float64), _c(b, np.float64)
+    n = rowptr.size - 1
+    x = np.zeros(n) if x0 is None else _c(x0, np.float64).copy()
+    info = SolveInfo()
+    norms = np.full(maxit + 1, np.nan) if want_norms else None
+    lib().orc_gmres(n, rowptr, col, val, b, x, tol, maxit, k_dim, int(omp), C.byref(info),
+                    norms.ctypes.data if want_norms else None)
+    out = dict(x=x, iterations=info.iterations, rel_res_norm=info.rel_res_norm, converged=info.converged)
+    if want_norms:
+        out["norms"] = norms[: info.iterations + 1]
     return out
 
 

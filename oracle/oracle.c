@@ -587,3 +587,108 @@ done:
   info->rel_res_norm = bi_prod > 0.0 ? sqrt(i_prod / bi_prod) : 0.0;
   free(trp); free(tci); free(tv); free(r); free(p); free(q); free(t);
 }
+
+/* ---- GMRES(k) (solver id 12, solvers.c:1183-1245: MaxIter, KDim = 30, Tol, identity preconditioner) ----
+ * Restatement of the published hypre_GMRESSolve loop: Arnoldi with modified Gram-Schmidt, Givens
+ * rotations on the Hessenberg column as it arrives, |rs[i]| as the residual estimate, solution update
+ * x += sum_j y_j p_j at the end of a cycle, then -- if the estimate passed -- the true residual
+ * b - A x decides; otherwise the residual vector for the next cycle is rebuilt from the basis with
+ * the rotations (no extra product), exactly in hypre's order of operations.
+ * rel_res_norm = r_norm/||b||.  PARITY UNPINNED. */
+void orc_gmres(uint32_t n, const int *rowptr, const int *col, const double *val, const double *b,
+               double *x, double tol, int maxit, int k_dim, int use_omp, orc_solve_info *info, double *norms) {
+  const double epsmac = 1.e-16;
+  double **p = (double **)malloc(sizeof(double *) * (size_t)(k_dim + 1));
+  for (int j = 0; j <= k_dim; j++) p[j] = (double *)malloc(sizeof(double) * n);
+  double *w = (double *)malloc(sizeof(double) * n), *r = (double *)malloc(sizeof(double) * n);
+  double *rs = (double *)calloc((size_t)k_dim + 1, sizeof(double)), *c = (double *)calloc((size_t)k_dim, sizeof(double));
+  double *sn = (double *)calloc((size_t)k_dim, sizeof(double));
+  double *hh = (double *)calloc((size_t)(k_dim + 1) * k_dim, sizeof(double));
+#define HH(a, bb) hh[(size_t)(a) * k_dim + (bb)]
+  info->iterations = 0; info->converged = 0; info->breakdown = 0; info->rel_res_norm = 0.0;
+  const double b_norm = sqrt(v_dot(n, b, b, use_omp));
+  memcpy(p[0], b, sizeof(double) * n);
+  spmv(n, rowptr, col, val, -1.0, x, 1.0, p[0], use_omp);
+  double r_norm = sqrt(v_dot(n, p[0], p[0], use_omp));
+  if (norms) norms[0] = r_norm;
+  const double den_norm = b_norm > 0.0 ? b_norm : r_norm;
+  const double epsilon = tol * den_norm;
+  long long iter = 0;
+  while (iter < maxit) {
+    rs[0] = r_norm;
+    if (r_norm == 0.0) break;
+    if (r_norm <= epsilon) {   /* already converged at the start of a cycle: confirm on the true residual */
+      memcpy(r, b, sizeof(double) * n);
+      spmv(n, rowptr, col, val, -1.0, x, 1.0, r, use_omp);
+      r_norm = sqrt(v_dot(n, r, r, use_omp));
+      if (r_norm <= epsilon) { info->converged = 1; break; }
+    }
+    double t = 1.0 / r_norm;
+    for (uint32_t k = 0; k < n; k++) p[0][k] *= t;
+    int i = 0;
+    while (i < k_dim && iter < maxit) {
+      i++; iter++;
+      spmv(n, rowptr, col, val, 1.0, p[i - 1], 0.0, p[i], use_omp);
+      for (int j = 0; j < i; j++) {
+        HH(j, i - 1) = v_dot(n, p[j], p[i], use_omp);
+        v_axpy(n, -HH(j, i - 1), p[j], p[i], use_omp);
+      }
+      t = sqrt(v_dot(n, p[i], p[i], use_omp));
+      HH(i, i - 1) = t;
+      if (t != 0.0) { t = 1.0 / t; for (uint32_t k = 0; k < n; k++) p[i][k] *= t; }
+      for (int j = 1; j < i; j++) {
+        t = HH(j - 1, i - 1);
+        HH(j - 1, i - 1) = sn[j - 1] * HH(j, i - 1) + c[j - 1] * t;
+        HH(j, i - 1) = -sn[j - 1] * t + c[j - 1] * HH(j, i - 1);
+      }
+      t = HH(i, i - 1) * HH(i, i - 1);
+      t += HH(i - 1, i - 1) * HH(i - 1, i - 1);
+      double gamma = sqrt(t);
+      if (gamma == 0.0) gamma = epsmac;
+      c[i - 1] = HH(i - 1, i - 1) / gamma;
+      sn[i - 1] = HH(i, i - 1) / gamma;
+      rs[i] = -HH(i, i - 1) * rs[i - 1];
+      rs[i] /= gamma;
+      rs[i - 1] = c[i - 1] * rs[i - 1];
+      HH(i - 1, i - 1) = sn[i - 1] * HH(i, i - 1) + c[i - 1] * HH(i - 1, i - 1);
+      r_norm = fabs(rs[i]);
+      if (norms) norms[iter] = r_norm;
+      if (r_norm <= epsilon) break;
+    }
+    /* solve the triangular system, update x */
+    rs[i - 1] = rs[i - 1] / HH(i - 1, i - 1);
+    for (int k = i - 2; k >= 0; k--) {
+      t = 0.0;
+      for (int j = k + 1; j < i; j++) t -= HH(k, j) * rs[j];
+      t += rs[k];
+      rs[k] = t / HH(k, k);
+    }
+    for (uint32_t k = 0; k < n; k++) w[k] = rs[i - 1] * p[i - 1][k];
+    for (int j = i - 2; j >= 0; j--) v_axpy(n, rs[j], p[j], w, use_omp);
+    v_axpy(n, 1.0, w, x, use_omp);
+    if (r_norm <= epsilon) {
+      memcpy(r, b, sizeof(double) * n);
+      spmv(n, rowptr, col, val, -1.0, x, 1.0, r, use_omp);
+      r_norm = sqrt(v_dot(n, r, r, use_omp));
+      if (r_norm <= epsilon) { info->converged = 1; break; }
+      memcpy(p[0], r, sizeof(double) * n);   /* false convergence: restart from the true residual */
+      continue;
+    }
+    /* residual vector of the next cycle from the basis and the rotations */
+    for (int j = i; j > 0; j--) {
+      rs[j - 1] = -sn[j - 1] * rs[j];
+      rs[j] = c[j - 1] * rs[j];
+    }
+    if (i) v_axpy(n, rs[i] - 1.0, p[i], p[i], use_omp);
+    for (int j = i - 1; j > 0; j--) v_axpy(n, rs[j], p[j], p[i], use_omp);
+    if (i) {
+      v_axpy(n, rs[0] - 1.0, p[0], p[0], use_omp);
+      v_axpy(n, 1.0, p[i], p[0], use_omp);
+    }
+  }
+#undef HH
+  info->iterations = iter;
+  info->rel_res_norm = b_norm > 0.0 ? r_norm / b_norm : r_norm;
+  for (int j = 0; j <= k_dim; j++) free(p[j]);
+  free(p); free(w); free(r); free(rs); free(c); free(sn); free(hh);
+}

@@ -86,6 +86,11 @@ void orc_bicgstab(uint32_t n, const int *rowptr, const int *col, const double *v
 void orc_cgnr(uint32_t n, const int *rowptr, const int *col, const double *val, const double *b,
               double *x, double tol, int maxit, int use_omp, orc_solve_info *info, double *rel_norms);
 
+/* GMRES(k_dim) as solvers.c:1183-1245 drives it (solver id 12: maxit, k_dim = 30, tol, identity preconditioner).
+ * norms may be NULL or hold maxit+1 doubles (absolute residual estimates). */
+void orc_gmres(uint32_t n, const int *rowptr, const int *col, const double *val, const double *b,
+               double *x, double tol, int maxit, int k_dim, int use_omp, orc_solve_info *info, double *norms);
+
 /* ---- synthetic matrices (bench.py / tests; same definitions as the device generators) */
 uint64_t orc_splitmix64(uint64_t x);
 /* R-MAT edge i of a 2^scale graph: row/col bits drawn from counter-based splitmix64 */

@@ -673,6 +673,54 @@ def test_cgnr_transpose_maxit_and_zero_rhs():
     assert r0["iterations"] == 0 and np.all(x0.get() == 0.0)
 
 
+# ------------------------------------------------------------------ GMRES(k) (solver id 12)
+@pytest.mark.parametrize("kind,dims,k_dim,kernel", [(5, (48, 40, 1), 30, None), (7, (16, 14, 12), 30, None),
+                                                    (7, (16, 14, 12), 5, None), (7, (32, 16, 10), 30, "sweep")])
+def test_gmres_matches_oracle(kind, dims, k_dim, kernel):
+    rp, ci, v, n = _convection_diffusion(kind, dims)
+    bh = np.random.default_rng(14).normal(size=n)
+    tol = 1e-9
+    o = oracle.gmres(rp, ci, v, bh, tol=tol, maxit=2000, k_dim=k_dim, want_norms=True)
+    A = mk.Matrix.from_csr(n, n, rp, ci, v)
+    if kernel == "sweep":
+        A.set_spmv_kernel(mk.SPMV_SWEEP)
+    b, x = mk.Vector(n, values=bh), mk.Vector(n, fill=0.0)
+    S = mk.GMRES(max_iter=2000, tol=tol, k_dim=k_dim, logging=1)
+    S.setup(A, b, x)
+    res = S.solve(A, b, x)
+    assert res["converged"] == 1 == o["converged"]
+    assert abs(res["iterations"] - o["iterations"]) <= max(CG_ITER_TOL, 0.02 * o["iterations"]), (res, o["iterations"])
+    xs = x.get()
+    true_rel = np.linalg.norm(bh - oracle.csr_spmv(rp, ci, v, xs)) / np.linalg.norm(bh)
+    assert true_rel <= tol * 1.0001 and abs(res["rel_res_norm"] - true_rel) <= 1e-3 * tol
+    assert np.linalg.norm(xs - o["x"]) <= 1e-6 * np.linalg.norm(o["x"])
+    hist = S.residual_history(4000)
+    assert hist.size == res["iterations"] + 1
+    m = min(hist.size, o["norms"].size, 2 * k_dim + 5)      # across at least one restart
+    assert np.allclose(hist[:m], o["norms"][:m], rtol=1e-7)
+
+
+def test_gmres_maxit_restart_and_zero_residual():
+    rp, ci, v, n = _convection_diffusion(5, (40, 40, 1))
+    A = mk.Matrix.from_csr(n, n, rp, ci, v)
+    b, x = mk.Vector(n, fill=1.0), mk.Vector(n, fill=0.0)
+    S = mk.GMRES(max_iter=7, tol=1e-14, k_dim=3)           # 2 full cycles + 1 iteration
+    S.setup(A, b, x)
+    res = S.solve(A, b, x)
+    o = oracle.gmres(rp, ci, v, np.ones(n), tol=1e-14, maxit=7, k_dim=3)
+    assert res["iterations"] == 7 and res["converged"] == 0
+    assert np.isclose(res["rel_res_norm"], o["rel_res_norm"], rtol=1e-9)
+    assert np.allclose(x.get(), o["x"], rtol=1e-9, atol=1e-13)
+    res2 = S.solve(A, b, x)                                 # niter > 1: continue from the previous x
+    o2 = oracle.gmres(rp, ci, v, np.ones(n), x0=o["x"], tol=1e-14, maxit=7, k_dim=3)
+    assert np.isclose(res2["rel_res_norm"], o2["rel_res_norm"], rtol=1e-8)
+    b0, x0 = mk.Vector(n, fill=0.0), mk.Vector(n, fill=0.0)
+    r0 = S.solve(A, b0, x0)                                 # zero residual at the start: nothing to do
+    assert r0["iterations"] == 0 and np.all(x0.get() == 0.0)
+    with pytest.raises(mk.MkError):
+        mk.GMRES(k_dim=100)
+
+
 @pytest.mark.parametrize("check_every", [1, 5])
 def test_jacobi_banded_matches_oracle(check_every):
     # config 5 shape scaled down

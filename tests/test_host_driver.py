@@ -241,6 +241,22 @@ def test_driver_cgnr_output_lines(tmp_path):
 
 
 @pytest.mark.gpu
+def test_driver_gmres_output_lines(tmp_path):
+    # solver id 12 (solvers.c:1183-1245), restart 30
+    mtx = tmp_path / "poisson.mtx"
+    rp, ci, v = _write_poisson(mtx, 48, 40, shuffle_seed=5)
+    out = subprocess.run([os.path.join(HOST, "solver"), "-solver", "12", "-mtx", str(mtx), "-tol", "1e-8",
+                          "-maxit", "2000", "-log", "0"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert re.search(r"^GMRES Setup time = [0-9.]+ seconds$", out.stdout, re.M)
+    assert re.search(r"^GMRES Solve time = [0-9.]+ seconds$", out.stdout, re.M)
+    it = int(re.search(r"^Iterations = (\d+)$", out.stdout, re.M).group(1))
+    nrm = float(re.search(r"^Final Relative Residual Norm = ([0-9.e+-]+)$", out.stdout, re.M).group(1))
+    o = oracle.gmres(rp, ci, v, np.ones(rp.size - 1), tol=1e-8, maxit=2000, k_dim=30)
+    assert abs(it - o["iterations"]) <= max(2, 0.02 * o["iterations"]) and nrm <= 1e-8
+
+
+@pytest.mark.gpu
 def test_driver_binary_cache(tmp_path):
     mtx = tmp_path / "poisson.mtx"
     _write_poisson(mtx, 40, 40, shuffle_seed=2)
