@@ -126,16 +126,32 @@ int mk_pcg_solve(mk_pcg *S, const mk_matrix *A, const mk_vector *b, mk_vector *x
   // inner products.
   static const int no_fused = getenv("MK_NO_FUSED_CG") ? atoi(getenv("MK_NO_FUSED_CG")) : 0;
   const bool fused = (A->kernel == MK_SPMV_SWEEP) && !no_fused;
+  // ... and K3 rides in the window fill of the first sweep of the NEXT step (p' = z + beta p computed while the
+  // window is loaded, the block's own rows written to the other p buffer; S->s is free for that): the 24 B/row of
+  // K3 become 16 B/row more in a sweep that was bound by instruction issue, not bytes.  With the Jacobi
+  // preconditioner this needs 1/diag to be one number (every row keeps the single diagonal entry of the pattern).
+  double *pcur = S->p, *palt = S->s;
+  double zscale = 1.0;
+  static const int no_pfuse = getenv("MK_NO_FUSED_K3") ? atoi(getenv("MK_NO_FUSED_K3")) : 0;
+  const bool fuse_p = fused && !no_pfuse && (!dinv || sweep_uniform_diag(A, &zscale));
+  int nb2 = 0;
   for (int it = 0; it < S->max_iter && !stop; it++) {
     int nb1 = 0;
     if (fused) {
-      int nb2 = 0;
-      MK_TRY(launch_sweep_cg_dots(A, S->p, S->slab1, S->state, &nb1));
-      MK_TRY(launch_sweep_cg_resid_x(A, S->p, S->r, x->d, dinv, S->slab1, nb1, kSlabStride, S->slab2, S->state, &nb2));
-      if (dinv)
-        hipLaunchKernelGGL((pcg_update_p_kernel<true>), dim3(vb), dim3(kVecThreads), 0, c.stream, n, S->r, dinv, S->p, S->slab2, nb2, kSlabStride, S->two_norm, S->rel_change, S->state, S->norms);
-      else
-        hipLaunchKernelGGL((pcg_update_p_kernel<false>), dim3(vb), dim3(kVecThreads), 0, c.stream, n, S->r, dinv, S->p, S->slab2, nb2, kSlabStride, S->two_norm, S->rel_change, S->state, S->norms);
+      if (fuse_p && it > 0) {
+        MK_TRY(launch_sweep_cg_pdots(A, S->r, pcur, palt, zscale, S->slab2, nb2, kSlabStride, S->slab1, S->state, S->two_norm,
+                                     S->rel_change, S->norms, &nb1));
+        std::swap(pcur, palt);
+      } else {
+        MK_TRY(launch_sweep_cg_dots(A, pcur, S->slab1, S->state, &nb1));
+      }
+      MK_TRY(launch_sweep_cg_resid_x(A, pcur, S->r, x->d, dinv, S->slab1, nb1, kSlabStride, S->slab2, S->state, &nb2));
+      if (!fuse_p) {
+        if (dinv)
+          hipLaunchKernelGGL((pcg_update_p_kernel<true>), dim3(vb), dim3(kVecThreads), 0, c.stream, n, S->r, dinv, pcur, S->slab2, nb2, kSlabStride, S->two_norm, S->rel_change, S->state, S->norms);
+        else
+          hipLaunchKernelGGL((pcg_update_p_kernel<false>), dim3(vb), dim3(kVecThreads), 0, c.stream, n, S->r, dinv, pcur, S->slab2, nb2, kSlabStride, S->two_norm, S->rel_change, S->state, S->norms);
+      }
     } else {
     MK_TRY(launch_spmv_dot(A, S->p, S->s, S->slab1, &S->state->done, &nb1));
     if (dinv) {
@@ -161,6 +177,8 @@ int mk_pcg_solve(mk_pcg *S, const mk_matrix *A, const mk_vector *b, mk_vector *x
       }
     }
   }
+  if (fuse_p && S->max_iter > 0)   // the test that the next step's first kernel would have made (K3's prologue; n = 0: no p update)
+    hipLaunchKernelGGL((pcg_update_p_kernel<false>), dim3(1), dim3(kVecThreads), 0, c.stream, (int64_t)0, S->r, (const double *)nullptr, pcur, S->slab2, nb2, kSlabStride, S->two_norm, S->rel_change, S->state, S->norms);
   MK_HIP(hipGetLastError());
   MK_HIP(hipMemcpyAsync(&hst[0], S->state, sizeof(PcgState), hipMemcpyDeviceToHost, c.stream));
   MK_HIP(hipStreamSynchronize(c.stream));

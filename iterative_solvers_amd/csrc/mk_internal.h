@@ -69,6 +69,7 @@ inline void dev_free(void *p) {
 struct SweepArgs {
   int len;        // entries of the base pattern
   int P;          // rows between consecutive sweep steps of a block (even); == C in contiguous mode
+  int C;          // rows per chunk (512 or 1024 = two per lane of a 256- or 512-thread block)
   int ncp;        // chunks of C rows per plane
   int nseg;       // segments the K planes are cut into (grid = ncp * nseg blocks, set per launch)
   int wlo, sw;    // window: rows [r0 - wlo, r0 - wlo + sw) of a plane per slab (both even)
@@ -139,7 +140,9 @@ struct mk_matrix {
   unsigned *pmask = nullptr;       // device, npat: which entries of the base pattern each pattern keeps
   mk::SweepEntry *etab = nullptr;  // device, 32 entries
   bool sweep_auto = false;         // enough parallelism for the sweep kernel to be the default
-  mutable int sweep_bpc[5] = {0, 0, 0, 0, 0};
+  mutable int sweep_bpc[6] = {0, 0, 0, 0, 0, 0};
+  mutable int sweep_lds_set[6] = {0, 0, 0, 0, 0, 0};   // dynamic LDS above 48 KB needs a one-time opt-in per kernel
+  bool sweep_diag_uniform = false; // every row has the (single) diagonal entry of the base pattern
   int npat = 0, pml = 0;
   int max_off = 0;                 // largest |column - row| over all patterns
   // split kernel: chunk c covers entries [c*kSplitChunk, (c+1)*kSplitChunk); chunk_row[c] = first row starting in it
@@ -180,6 +183,13 @@ int launch_jacobi_sweep(const mk_matrix *A, const double *rhs, const double *ext
 //   resid_x: r -= alpha * A p with alpha = gamma / <A p,p> from slab_in (stride_in between its two components: 1 for
 //            an all-reduced pair), x += alpha p, partials of <r,z>, <r,r>, <x,x>
 int launch_sweep_cg_dots(const mk_matrix *A, const double *p, double *slab_out, PcgState *st, int *nblocks);
+//   pdots  : K3 folded into the window fill of `dots`: prologue = K3's (gamma', convergence test, beta from slab_in, 3
+//            components), p_new = zscale * r + beta * p_old written for the block's own rows and used as the window,
+//            then the partials of <A p_new, p_new>, <p_new, p_new>.  zscale = 1, or 1/diag when sweep_uniform_diag().
+int launch_sweep_cg_pdots(const mk_matrix *A, const double *r, const double *p_old, double *p_new, double zscale,
+                          const double *slab_in, int nblocks_in, int stride_in, double *slab_out, PcgState *st, int two_norm,
+                          int rel_change, double *norms, int *nblocks);
+int sweep_uniform_diag(const mk_matrix *A, double *inv_diag);
 int launch_sweep_cg_resid_x(const mk_matrix *A, const double *p, double *r, double *x, const double *dinv, const double *slab_in,
                             int nblocks_in, int stride_in, double *slab_out, PcgState *st, int *nblocks);
 

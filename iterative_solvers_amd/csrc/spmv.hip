@@ -178,10 +178,11 @@ __global__ void pat_verify_kernel(int64_t nrows, const int *__restrict__ rowptr,
 constexpr int kPatMaxValBytes = 32768;
 constexpr int kPatternChunkRows = 2 * kThreads;   // pattern kernel: rows per chunk   // value table (doubles) beside the offset table in LDS
 
-constexpr int kSweepC = 2 * kThreads;   // rows per chunk of the sweep kernel (two per lane)
+// rows per chunk of the sweep kernel = two per lane: 512 with 256 threads, or 1024 with 512 threads when the halo
+// (wlo + whi) is at least 512 entries -- the window is then 2x the chunk instead of 3x, and the L2 -> LDS fill,
+// which bounds these kernels at ~9 TB/s summed over the CUs, shrinks by a third
 constexpr int kSweepNS = 4;             // ring slots: planes k-1, k, k+1 and the one being written
-constexpr int kSweepNL = 4;             // 16-byte loads per thread per slab -> window <= 2048 entries
-constexpr int kSweepMaxLds = 64 * 1024 - 512;
+constexpr int kSweepMaxSw = 2048;        // window entries per slab (LDS = 4 slabs x 8 B x this = 64 KB)
 
 // Can the sweep kernel serve this matrix?  tab/vals: the (offsets, values) pattern table.
 static int plan_sweep(mk_matrix *A, const std::vector<int> &tab, const std::vector<double> &vals) {
@@ -213,8 +214,8 @@ static int plan_sweep(mk_matrix *A, const std::vector<int> &tab, const std::vect
   S.len = len;
   int maxabs = 0;
   for (int u = 0; u < len; u++) maxabs = std::max(maxabs, std::abs(off_of(base, u)));
-  if (maxabs <= 768) {   // banded: contiguous sweep, every offset is "near"
-    S.P = kSweepC;
+  const bool contiguous = (maxabs <= 768);
+  if (contiguous) {   // banded: contiguous sweep, every offset is "near"; P = chunk size, set below
     for (int u = 0; u < len; u++) { ea[u] = 0; eb[u] = off_of(base, u); }
   } else {
     // far offsets cluster around +-P: P = centre of the cluster that holds the largest |offset|
@@ -243,11 +244,14 @@ static int plan_sweep(mk_matrix *A, const std::vector<int> &tab, const std::vect
   }
   S.wlo = (-bmin + 1) & ~1;
   const int whi = (bmax + 1) & ~1;
-  S.sw = kSweepC + S.wlo + whi;
-  if (S.sw > 2 * kThreads * kSweepNL) return MK_OK;
-  if ((size_t)kSweepNS * S.sw * 8 + (size_t)npat * 4 > (size_t)kSweepMaxLds) return MK_OK;
+  static const int env_c = getenv("MK_SWEEP_C") ? atoi(getenv("MK_SWEEP_C")) : 0;
+  S.C = (env_c == 512 || env_c == 1024) ? env_c : (S.wlo + whi >= 512 ? 1024 : 512);
+  if (S.C == 1024 && S.C + S.wlo + whi > kSweepMaxSw) S.C = 512;
+  S.sw = S.C + S.wlo + whi;
+  if (S.sw > kSweepMaxSw) return MK_OK;
+  if (contiguous) S.P = S.C;
   S.K = (int)((A->nrows + S.P - 1) / S.P);
-  S.ncp = (S.P + kSweepC - 1) / kSweepC;
+  S.ncp = (S.P + S.C - 1) / S.C;
   S.nseg = 1;
   MK_TRY(dev_alloc(&A->pmask, (size_t)npat));
   MK_TRY(dev_alloc(&A->etab, 4 * 32));
@@ -262,6 +266,12 @@ static int plan_sweep(mk_matrix *A, const std::vector<int> &tab, const std::vect
   MK_HIP(hipMemcpyAsync(A->etab, E, sizeof(E), hipMemcpyHostToDevice, ctx().stream));
   MK_HIP(hipStreamSynchronize(ctx().stream));
   A->sweep = new SweepArgs(S);
+  // one diagonal entry in the base pattern and every row keeps it: 1/diag is one number (fused Jacobi-PCG step)
+  int ndiag = 0;
+  for (int u = 0; u < len; u++) ndiag += (off_of(base, u) == 0);
+  bool all_have = (ndiag == 1);
+  for (int q = 0; q < npat && all_have; q++) all_have = (mask[q] >> S.diag) & 1u;
+  A->sweep_diag_uniform = all_have;
   // default only when the grid can fill the chip: ncp chunks per plane times segments of >= 8 planes
   A->sweep_auto = (int64_t)S.ncp * std::max(1, S.K / 8) >= 2 * (int64_t)ctx().num_cus;
   return MK_OK;
@@ -1011,20 +1021,25 @@ static int launch_pattern(const mk_matrix *A, double alpha, const double *x, dou
 // kept ~7 x 8 B per row in flight in registers and was bound by latency x register file, here one
 // 8-byte stream per row feeds LDS and HBM sees x once.  Rows and entries are summed in the order
 // of the CSR arrays (a sub-list keeps the base's order) -> bitwise identical to the serial reference.
-template <int MODE, int NL>   // NL = 16-byte loads per thread per slab = ceil(sw / 512)
-__global__ __launch_bounds__(kThreads) void spmv_sweep_kernel(
+template <int MODE, int NL, int T>   // T threads, chunk = 2 T rows; NL = 16-byte loads per thread per slab = ceil(sw / 2T)
+__global__ __launch_bounds__(T, T == 512 ? 2 : 1) void spmv_sweep_kernel(
     const SweepArgs S, const SweepEntry *__restrict__ etab, int64_t nrows, int64_t ncols, const unsigned short *__restrict__ pat,
     const unsigned *__restrict__ pmask, int npat, const double *__restrict__ x, double *__restrict__ y, double alpha, double beta, double *__restrict__ slab,
     const int *__restrict__ done, const double *__restrict__ rhs, const double *__restrict__ extra,
-    PcgState *st, const double *__restrict__ slab_in, int nblocks_in, int stride_in, double *__restrict__ xupd) {
+    PcgState *st, const double *__restrict__ slab_in, int nblocks_in, int stride_in, double *__restrict__ xupd,
+    int flags, double *__restrict__ norms) {
   // MODE 0: y = alpha A x + beta y.  1: y = A x, partials of <y,x>, <x,x>.  2: Jacobi sweep.
   // MODE 3 (fused CG, first kernel of a step): partials of <A x, x>, <x,x> only, nothing stored.
   // MODE 4 (second kernel; x is CG's p): alpha = gamma / <A x, x> from slab_in (K2's prologue), then
   //         rhs (= y = the residual r) <- r - alpha A x, xupd += alpha x (the solution update: x is in the window
   //         anyway), partials of <r,z>, <r,r>, <xupd,xupd>; `extra` = 1/diag when the Jacobi preconditioner is on.
+  // MODE 5 (first kernel of every step but the first): K3 rides in the window fill.  Prologue = K3's (gamma', the
+  //         convergence test, beta from slab_in); the window is filled with p' = z + beta x (z = alpha * rhs, alpha = 1
+  //         or the uniform 1/diag) instead of x, the block's own rows of p' go to y, then as MODE 3 on p'.
+  //         flags: bit 0 two_norm, bit 1 rel_change.
   if (done != nullptr && *done != 0) return;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  constexpr int C = kSweepC, NS = kSweepNS;
+  constexpr int C = 2 * T, NS = kSweepNS;
   const int sw = S.sw;
   double *ring = reinterpret_cast<double *>(smem_raw);            // NS slabs of sw entries
   unsigned *smask = reinterpret_cast<unsigned *>(ring + NS * sw);   // npat
@@ -1034,7 +1049,7 @@ __global__ __launch_bounds__(kThreads) void spmv_sweep_kernel(
     if (MODE == 4) {   // K2's prologue
       const bool leader = (blockIdx.x == 0 && tid == 0);
       double d[2];
-      reduce_slab<2, kThreads>(slab_in, nblocks_in, stride_in, d, ring);
+      reduce_slab<2, T>(slab_in, nblocks_in, stride_in, d, ring);
       const double sdotp = d[0], gamma = st->gamma;
       __syncthreads();
       if (sdotp == 0.0) {
@@ -1048,9 +1063,34 @@ __global__ __launch_bounds__(kThreads) void spmv_sweep_kernel(
       }
       if (leader) { st->alpha = alpha; st->gamma_old = gamma; st->pp = d[1]; st->sdotp = sdotp; st->iter += 1; }
     }
+    if (MODE == 5) {   // K3's prologue
+      const bool leader = (blockIdx.x == 0 && tid == 0);
+      double d[3];
+      reduce_slab<3, T>(slab_in, nblocks_in, stride_in, d, ring);
+      const double gamma_new = d[0];
+      const double i_prod = (flags & 1) ? d[1] : d[0];
+      const double xx = d[2];
+      const double bi_prod = st->bi_prod, eps = st->eps, al = st->alpha, pp = st->pp, gamma_old = st->gamma_old;
+      __syncthreads();
+      bool conv = (i_prod / bi_prod < eps);
+      if (conv && (flags & 2) && i_prod > 0.0) {
+        const double ratio = al * al * pp / xx;
+        if (ratio >= eps) conv = false;
+      }
+      const bool tiny_gamma = (gamma_new < DBL_MIN) && (-gamma_new < DBL_MIN);
+      if (leader) {
+        st->gamma = gamma_new;
+        st->i_prod = i_prod;
+        if (norms) norms[st->iter] = sqrt(i_prod / bi_prod);
+        if (conv) { st->converged = 1; st->done = 1; }
+        else if (tiny_gamma) { st->breakdown = 3; st->done = 2; }
+      }
+      if (conv || tiny_gamma) return;
+      beta = gamma_new / gamma_old;
+    }
     __syncthreads();   // ring was reduction scratch
   }
-  for (int i = tid; i < npat; i += kThreads) smask[i] = pmask[i];
+  for (int i = tid; i < npat; i += T) smask[i] = pmask[i];
   const int nb = gridDim.x;   // multiple of 8; blocks of one XCD take neighbouring chunks of a plane (shared halos in its L2)
   const int lid = (blockIdx.x & 7) * (nb >> 3) + (blockIdx.x >> 3);
   double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
@@ -1070,19 +1110,39 @@ __global__ __launch_bounds__(kThreads) void spmv_sweep_kernel(
     // row refers to (their mask bit is clear) or are never read.
     const int xlast = ((int)ncols - 1) & ~1;   // x[xlast], x[xlast+1]: inside the allocation (slack behind ncols)
     const int rlast = (nr - 1) & ~1;
-    auto load_slab = [&](int j, d2_t(&reg)[NL]) {   // window of plane j
+    constexpr int NLR = (MODE == 5) ? NL : 1;   // second window stream (the residual) only in MODE 5
+    auto load_slab = [&](int j, d2_t(&reg)[NL], d2_t(&regr)[NLR]) {   // window of plane j
       const int g0 = min(j, k1) * S.P + r0 - S.wlo + lr;
 #pragma unroll
       for (int i = 0; i < NL; i++) {
-        const int g = min(max(g0 + i * 2 * kThreads, 0), xlast);
+        const int g = min(max(g0 + i * 2 * T, 0), xlast);
         reg[i] = *reinterpret_cast<const d2_t *>(reinterpret_cast<const char *>(x) + ((unsigned)g << 3));
+        if (MODE == 5) regr[i] = *reinterpret_cast<const d2_t *>(reinterpret_cast<const char *>(rhs) + ((unsigned)g << 3));
       }
     };
-    auto write_slab = [&](int slot, const d2_t(&reg)[NL]) {
+    auto write_slab = [&](int slot, int j, const d2_t(&reg)[NL], const d2_t(&regr)[NLR]) {
       double *dst = ring + slot * sw + lr;
 #pragma unroll
-      for (int i = 0; i < NL; i++)
-        if (lr + i * 2 * kThreads < sw) *reinterpret_cast<d2_t *>(dst + i * 2 * kThreads) = reg[i];
+      for (int i = 0; i < NL; i++) {
+        const int wi = lr + i * 2 * T;   // position in the window
+        if (wi < sw) {
+          d2_t v = reg[i];
+          if (MODE == 5) {
+            d2_t z = regr[i];
+            z.x *= alpha;
+            z.y *= alpha;
+            v.x = beta * v.x + z.x;   // K3: p = beta p + z
+            v.y = beta * v.y + z.y;
+            const int own = wi - S.wlo;   // the block's own rows of its own planes go to the new p
+            if (j >= k0 && j < k1 && own >= 0 && own < rows_here) {
+              const int g = j * S.P + r0 + own;
+              if (g + 1 < nr) *reinterpret_cast<d2_t *>(reinterpret_cast<char *>(y) + ((unsigned)g << 3)) = v;
+              else if (g < nr) *reinterpret_cast<double *>(reinterpret_cast<char *>(y) + ((unsigned)g << 3)) = v.x;
+            }
+          }
+          *reinterpret_cast<d2_t *>(dst + i * 2 * T) = v;
+        }
+      }
     };
     auto row_of = [&](int j) -> int { return j * S.P + r0 + lr; };
     auto live = [&](int j) -> bool { return j < k1 && lr < rows_here && row_of(j) < nr; };
@@ -1100,13 +1160,13 @@ __global__ __launch_bounds__(kThreads) void spmv_sweep_kernel(
     // Three register stages, each used in place: stage (k mod 3) holds slab k+2 at step k, is written to the
     // ring and at once re-loaded with slab k+5 -- no register-to-register rotation (a move of a register
     // that a load is still filling would wait for that load and serialise the pipeline).
-    d2_t st0[NL], st1[NL], st2[NL];
-    load_slab(k0 - 1, st0);
-    load_slab(k0, st1);
-    load_slab(k0 + 1, st2);
-    write_slab(0, st0);
-    write_slab(1, st1);
-    write_slab(2, st2);
+    d2_t st0[NL], st1[NL], st2[NL], rt0[NLR], rt1[NLR], rt2[NLR];
+    load_slab(k0 - 1, st0, rt0);
+    load_slab(k0, st1, rt1);
+    load_slab(k0 + 1, st2, rt2);
+    write_slab(0, k0 - 1, st0, rt0);
+    write_slab(1, k0, st1, rt1);
+    write_slab(2, k0 + 1, st2, rt2);
     // issue order as in the steady state (ids/aux of a plane, then the slab two planes further): the compiler
     // derives "how many younger loads may stay in flight" from the worst path into the loop, the prologue included
     d2_t ax0 = {0.0, 0.0}, ax1 = ax0, ax2 = ax0, ex0 = ax0, ex1 = ax0, ex2 = ax0;
@@ -1115,20 +1175,20 @@ __global__ __launch_bounds__(kThreads) void spmv_sweep_kernel(
     if (aux) ax0 = load_pair(aux, k0);
     if (kExtra && extra) ex0 = load_pair(extra, k0);
     if (MODE == 4) xu0 = load_pair(xupd, k0);
-    load_slab(k0 + 2, st0);
+    load_slab(k0 + 2, st0, rt0);
     unsigned id1 = load_ids(k0 + 1);
     if (aux) ax1 = load_pair(aux, k0 + 1);
     if (kExtra && extra) ex1 = load_pair(extra, k0 + 1);
     if (MODE == 4) xu1 = load_pair(xupd, k0 + 1);
-    load_slab(k0 + 3, st1);
+    load_slab(k0 + 3, st1, rt1);
     unsigned id2 = load_ids(k0 + 2);
     if (aux) ax2 = load_pair(aux, k0 + 2);
     if (kExtra && extra) ex2 = load_pair(extra, k0 + 2);
     if (MODE == 4) xu2 = load_pair(xupd, k0 + 2);
-    load_slab(k0 + 4, st2);
+    load_slab(k0 + 4, st2, rt2);
     __syncthreads();
 
-    auto step = [&](int k, d2_t(&st)[NL], unsigned &idr, d2_t &axr, d2_t &exr, d2_t &xur) {
+    auto step = [&](int k, d2_t(&st)[NL], d2_t(&rt)[NLR], unsigned &idr, d2_t &axr, d2_t &exr, d2_t &xur) {
       const unsigned id0 = idr;
       const d2_t ax0 = axr, ex0 = exr, xu0 = xur;
       const int jb = (k - k0 + 1) & (NS - 1);   // ring slot of plane k
@@ -1216,31 +1276,31 @@ __global__ __launch_bounds__(kThreads) void spmv_sweep_kernel(
             if (two) { acc0 += s1 * xb; acc1 += xb * xb; }
           }
         }
-        if (MODE != 3) {
+        if (MODE != 3 && MODE != 5) {
           if (two) *reinterpret_cast<d2_t *>(reinterpret_cast<char *>(y) + ((unsigned)g << 3)) = out;
           else *reinterpret_cast<double *>(reinterpret_cast<char *>(y) + ((unsigned)g << 3)) = out.x;
         }
       }
       // slab k+2 (loaded three steps ago) into the slot plane k-2 occupied; nobody reads that slot in this step
-      write_slab((k - k0 + 3) & (NS - 1), st);
+      write_slab((k - k0 + 3) & (NS - 1), k + 2, st, rt);
       // look-ahead loads into the registers just consumed: ids / aux of plane k+3, slab k+5
       idr = load_ids(k + 3);
       if (aux) axr = load_pair(aux, k + 3);
       if (kExtra && extra) exr = load_pair(extra, k + 3);
       if (MODE == 4) xur = load_pair(xupd, k + 3);
-      load_slab(k + 5, st);
+      load_slab(k + 5, st, rt);
       __syncthreads();
     };
     for (int k = k0; k < k1; k += 3) {   // straight-line body: steps at or behind k1 compute nothing (live() is false)
-      step(k, st0, id0, ax0, ex0, xu0);
-      step(k + 1, st1, id1, ax1, ex1, xu1);
-      step(k + 2, st2, id2, ax2, ex2, xu2);
+      step(k, st0, rt0, id0, ax0, ex0, xu0);
+      step(k + 1, st1, rt1, id1, ax1, ex1, xu1);
+      step(k + 2, st2, rt2, id2, ax2, ex2, xu2);
     }
   }
   if (MODE != 0) {
     __syncthreads();
     double w[3] = {acc0, acc1, acc2};
-    block_sum<3, kThreads>(w, ring);
+    block_sum<3, T>(w, ring);
     if (threadIdx.x == 0) {
       slab[0 * kSlabStride + blockIdx.x] = w[0];
       if (MODE != 2) slab[1 * kSlabStride + blockIdx.x] = w[1];
@@ -1253,7 +1313,7 @@ template <int MODE>
 static int launch_sweep(const mk_matrix *A, double alpha, const double *x, double beta, double *y, double *slab,
                         const int *done, int *nblocks, const double *rhs = nullptr, const double *extra = nullptr,
                         PcgState *st = nullptr, const double *slab_in = nullptr, int nblocks_in = 0, int stride_in = kSlabStride,
-                        double *xupd = nullptr) {
+                        double *xupd = nullptr, int flags = 0, double *norms = nullptr) {
   Context &c = ctx();
   if (!A->sweep) return fail(MK_ERR_UNSUPPORTED, "spmv: the sweep kernel needs rows that are sub-lists of one pattern with offsets a*P + b");
   SweepArgs S = *A->sweep;
@@ -1262,7 +1322,8 @@ static int launch_sweep(const mk_matrix *A, double alpha, const double *x, doubl
   int per_cu = env_bpc > 0 ? env_bpc : A->sweep_bpc[MODE];
   if (per_cu <= 0) {
     int occ = 0;
-    hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, spmv_sweep_kernel<MODE, 3>, kThreads, lds);
+    hipError_t oe = hipSuccess;
+    occ = (S.C == 1024) ? 2 : (int)std::min<size_t>(3, (size_t)(160 * 1024) / std::max<size_t>(lds, 1));   // LDS-bound: 160 KB per CU
     per_cu = (oe == hipSuccess && occ > 0) ? std::min(occ, 8) : 2;
     A->sweep_bpc[MODE] = per_cu;
   }
@@ -1278,20 +1339,24 @@ static int launch_sweep(const mk_matrix *A, double alpha, const double *x, doubl
   S.nseg = nseg;
   const int blocks = (S.ncp * nseg + 7) / 8 * 8;
   if (nblocks) *nblocks = blocks;
-  const int nl = std::max(2, (S.sw + 2 * kThreads - 1) / (2 * kThreads));
-#define MK_LAUNCH_SW(NLL)                                                                                                  \
-  case NLL:                                                                                                                \
-    hipLaunchKernelGGL((spmv_sweep_kernel<MODE, NLL>), dim3((unsigned)blocks), dim3(kThreads), lds, c.stream, S, A->etab, A->nrows, \
-                       A->ncols, A->pat, A->pmask, A->npat, x, y, alpha, beta, slab, done, rhs, extra, st, slab_in,       \
-                       nblocks_in, stride_in, xupd);                                                                                        \
-    break;
-  switch (nl) {
-    MK_LAUNCH_SW(2)
-    MK_LAUNCH_SW(3)
-    MK_LAUNCH_SW(4)
-    default:
-      return fail(MK_ERR_UNSUPPORTED, "spmv: sweep window of %d entries", S.sw);
+  const int T = S.C / 2;
+  const int nl = std::max(2, (S.sw + 2 * T - 1) / (2 * T));
+#define MK_LAUNCH_SW(NLL, TT)                                                                                              \
+  {                                                                                                                        \
+    auto kern = spmv_sweep_kernel<MODE, NLL, TT>;                                                                          \
+    if (lds > 48 * 1024 && !A->sweep_lds_set[MODE]) {                                                                      \
+      MK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+      A->sweep_lds_set[MODE] = 1;                                                                                          \
+    }                                                                                                                      \
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(TT), lds, c.stream, S, A->etab, A->nrows, A->ncols, A->pat,     \
+                       A->pmask, A->npat, x, y, alpha, beta, slab, done, rhs, extra, st, slab_in, nblocks_in, stride_in,  \
+                       xupd, flags, norms);                                                                                \
   }
+  if (T == 256 && nl == 2) MK_LAUNCH_SW(2, 256)
+  else if (T == 256 && nl == 3) MK_LAUNCH_SW(3, 256)
+  else if (T == 256 && nl == 4) MK_LAUNCH_SW(4, 256)
+  else if (T == 512 && nl == 2) MK_LAUNCH_SW(2, 512)
+  else return fail(MK_ERR_UNSUPPORTED, "spmv: sweep window of %d entries for chunks of %d rows", S.sw, S.C);
 #undef MK_LAUNCH_SW
   MK_HIP(hipGetLastError());
   return MK_OK;
@@ -1488,6 +1553,19 @@ int launch_jacobi_sweep(const mk_matrix *A, const double *rhs, const double *ext
 
 int launch_sweep_cg_dots(const mk_matrix *A, const double *p, double *slab_out, PcgState *st, int *nblocks) {
   return launch_sweep<3>(A, 1.0, p, 0.0, nullptr, slab_out, nullptr, nblocks, nullptr, nullptr, st);
+}
+
+int sweep_uniform_diag(const mk_matrix *A, double *inv_diag) {
+  if (!A->sweep || !A->sweep_diag_uniform) return 0;
+  if (inv_diag) *inv_diag = 1.0 / A->sweep->dv;
+  return 1;
+}
+
+int launch_sweep_cg_pdots(const mk_matrix *A, const double *r, const double *p_old, double *p_new, double zscale,
+                          const double *slab_in, int nblocks_in, int stride_in, double *slab_out, PcgState *st, int two_norm,
+                          int rel_change, double *norms, int *nblocks) {
+  return launch_sweep<5>(A, zscale, p_old, 0.0, p_new, slab_out, nullptr, nblocks, r, nullptr, st, slab_in, nblocks_in, stride_in,
+                         nullptr, (two_norm ? 1 : 0) | (rel_change ? 2 : 0), norms);
 }
 
 int launch_sweep_cg_resid_x(const mk_matrix *A, const double *p, double *r, double *x, const double *dinv, const double *slab_in,
