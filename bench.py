@@ -139,9 +139,9 @@ def main():
     vec_bytes = (88 if precond else 72) * n     # K2 + K3: x, p, r, s (and 1/diag) streams
     iter_bytes = spmv_bytes + vec_bytes
     if info.kernel == 5 and not os.environ.get("MK_NO_FUSED_CG"):
-        # fused step on sweep matrices: dots of A p (2+8), r -= alpha A p recomputed and x += alpha p (2+8+16+16),
-        # p update (24); with the Jacobi preconditioner 1/diag is read by the last two
-        iter_bytes = (92 if precond else 76) * n
+        # fused step on sweep matrices: first sweep p' = z + beta p, dots of A p' (2 + 8 + 8 + 8 B/row), second sweep
+        # r -= alpha A p' recomputed, x += alpha p' (2 + 8 + 16 + 16); 1/diag is one number on these operators
+        iter_bytes = 68 * n
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):

@@ -245,10 +245,11 @@ static int plan_sweep(mk_matrix *A, const std::vector<int> &tab, const std::vect
   S.wlo = (-bmin + 1) & ~1;
   const int whi = (bmax + 1) & ~1;
   static const int env_c = getenv("MK_SWEEP_C") ? atoi(getenv("MK_SWEEP_C")) : 0;
-  S.C = (env_c == 512 || env_c == 1024) ? env_c : (S.wlo + whi >= 512 ? 1024 : 512);
+  S.C = (env_c == 512 || env_c == 1024 || env_c == 2048) ? env_c : (S.wlo + whi >= 512 ? 1024 : 512);
+  if (S.C == 2048 && S.C + S.wlo + whi > 4096) S.C = 1024;
   if (S.C == 1024 && S.C + S.wlo + whi > kSweepMaxSw) S.C = 512;
   S.sw = S.C + S.wlo + whi;
-  if (S.sw > kSweepMaxSw) return MK_OK;
+  if (S.sw > (S.C == 2048 ? 4096 : kSweepMaxSw)) return MK_OK;
   if (contiguous) S.P = S.C;
   S.K = (int)((A->nrows + S.P - 1) / S.P);
   S.ncp = (S.P + S.C - 1) / S.C;
@@ -1264,7 +1265,8 @@ __global__ __launch_bounds__(T, T == 512 ? 2 : 1) void spmv_sweep_kernel(
             rb -= alpha * s1;
             out.x = ra;
             out.y = rb;
-            const double za = extra ? ra * ex0.x : ra, zb = extra ? rb * ex0.y : rb;
+            // z = C r: 1/diag per row from `extra`, or one number (beta != 0) when the diagonal is uniform
+            const double za = extra ? ra * ex0.x : (beta != 0.0 ? ra * beta : ra), zb = extra ? rb * ex0.y : (beta != 0.0 ? rb * beta : rb);
             acc0 += ra * za;
             acc1 += ra * ra;
             if (two) { acc0 += rb * zb; acc1 += rb * rb; }
@@ -1323,7 +1325,7 @@ static int launch_sweep(const mk_matrix *A, double alpha, const double *x, doubl
   if (per_cu <= 0) {
     int occ = 0;
     hipError_t oe = hipSuccess;
-    occ = (S.C == 1024) ? 2 : (int)std::min<size_t>(3, (size_t)(160 * 1024) / std::max<size_t>(lds, 1));   // LDS-bound: 160 KB per CU
+    occ = (S.C == 2048) ? 1 : (S.C == 1024) ? 2 : (int)std::min<size_t>(3, (size_t)(160 * 1024) / std::max<size_t>(lds, 1));   // LDS-bound: 160 KB per CU
     per_cu = (oe == hipSuccess && occ > 0) ? std::min(occ, 8) : 2;
     A->sweep_bpc[MODE] = per_cu;
   }
@@ -1356,6 +1358,7 @@ static int launch_sweep(const mk_matrix *A, double alpha, const double *x, doubl
   else if (T == 256 && nl == 3) MK_LAUNCH_SW(3, 256)
   else if (T == 256 && nl == 4) MK_LAUNCH_SW(4, 256)
   else if (T == 512 && nl == 2) MK_LAUNCH_SW(2, 512)
+  else if (T == 1024 && nl == 2) MK_LAUNCH_SW(2, 1024)
   else return fail(MK_ERR_UNSUPPORTED, "spmv: sweep window of %d entries for chunks of %d rows", S.sw, S.C);
 #undef MK_LAUNCH_SW
   MK_HIP(hipGetLastError());
@@ -1570,7 +1573,9 @@ int launch_sweep_cg_pdots(const mk_matrix *A, const double *r, const double *p_o
 
 int launch_sweep_cg_resid_x(const mk_matrix *A, const double *p, double *r, double *x, const double *dinv, const double *slab_in,
                             int nblocks_in, int stride_in, double *slab_out, PcgState *st, int *nblocks) {
-  return launch_sweep<4>(A, 0.0, p, 0.0, r, slab_out, nullptr, nblocks, r, dinv, st, slab_in, nblocks_in, stride_in, x);
+  double zscale = 0.0;   // Jacobi preconditioner on a uniform diagonal: one number instead of an 8 B/row stream
+  if (dinv && sweep_uniform_diag(A, &zscale)) dinv = nullptr; else zscale = 0.0;
+  return launch_sweep<4>(A, 0.0, p, zscale, r, slab_out, nullptr, nblocks, r, dinv, st, slab_in, nblocks_in, stride_in, x);
 }
 
 int launch_spmv_dot(const mk_matrix *A, const double *x, double *y, double *slab, const int *done, int *nblocks) {
