@@ -249,6 +249,44 @@ def test_spmv_sweep_kernel(kind, dims):
     assert np.array_equal(res[mk.SPMV_SWEEP][3], res[mk.SPMV_PATTERN][3])      # Jacobi sweeps: same bits per row
 
 
+@pytest.mark.parametrize("n,hb", [(1, 1), (2, 1), (7, 3), (511, 2), (513, 3), (1025, 1), (100001, 3), (4099, 15)])
+def test_spmv_pattern_and_sweep_ragged_sizes(n, hb):
+    """odd row counts (a lane's second row missing), fewer rows than one chunk, rows shorter than the band at
+    both ends: pattern and sweep kernels against the serial reference, bit for bit; then whole solves"""
+    rp, ci, v = oracle.banded_csr(n, hb)
+    rng = np.random.default_rng(n)
+    xh = rng.normal(size=n)
+    ref = oracle.csr_spmv(rp, ci, v, xh)
+    A = mk.Matrix.from_csr(n, n, rp, ci, v)
+    kernels = [mk.SPMV_PATTERN, mk.SPMV_SWEEP] if A.info().value_patterns > 0 else []
+    assert kernels or n < 40                     # tiny matrices may have one pattern per row: no table
+    for k in kernels:
+        try:
+            A.set_spmv_kernel(k)
+        except mk.MkError:
+            assert k == mk.SPMV_SWEEP and n < 2 * hb + 1      # no interior row: no common base pattern
+            continue
+        x, y = mk.Vector(n, values=xh), mk.Vector(n, fill=-3.0)
+        A.spmv(x, y)
+        assert np.array_equal(y.get(), ref)
+        yx, xx = A.spmv_dot(x, y)
+        assert np.array_equal(y.get(), ref) and abs(yx - ref @ xh) <= 1e-12 * np.abs(ref * xh).sum()
+        _check_spmv(A, rp, ci, v, n, n, rng, alpha=-0.5, beta=2.0)
+        o = oracle.pcg(rp, ci, v, np.ones(n), tol=1e-10, precond=1, maxit=500)
+        b, x0 = mk.Vector(n, fill=1.0), mk.Vector(n, fill=0.0)
+        S = mk.PCG(max_iter=500, tol=1e-10, precond=mk.PRECOND_JACOBI)
+        S.setup(A, b, x0)
+        r = S.solve(A, b, x0)
+        assert r["converged"] == o["converged"] == 1 and abs(r["iterations"] - o["iterations"]) <= CG_ITER_TOL
+        assert np.linalg.norm(x0.get() - o["x"]) <= 1e-7 * np.linalg.norm(o["x"])
+        oj = oracle.jacobi(rp, ci, v, np.ones(n), tol=1e-30, maxit=25, check_every=5)
+        J = mk.Jacobi(max_iter=25, tol=1e-30, check_every=5)
+        xj = mk.Vector(n, fill=0.0)
+        J.setup(A, b, xj)
+        J.solve(A, b, xj)
+        assert np.allclose(xj.get(), oj["x"], rtol=1e-12, atol=0)
+
+
 def test_spmv_sweep_kernel_eligibility():
     rp, ci, v = oracle.stencil_csr(7, 31, 29, 3)           # plane of 899 rows: odd stride, a lane's two rows would straddle planes
     n = rp.size - 1
