@@ -190,6 +190,39 @@ __global__ void pack_kernel(int n, const int *__restrict__ idx, const double *__
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = v[idx[i]];
 }
 
+// What the neighbours need of p' = z + beta p BEFORE the sweep that forms p' has run (K3 folded into that sweep):
+// the rows of the send list, with beta worked out from the all-reduced <r,z>, <r,r>, <x,x> exactly as K3's
+// prologue does (same expression as the sweep -> the ghosts hold the owners' bits).  Reads only state fields that
+// the sweep's prologue, which may run at the same time on the other stream, does not write.
+struct HaloFuse {
+  const double *r = nullptr, *p_old = nullptr, *buf3 = nullptr;
+  const PcgState *st = nullptr;
+  double zscale = 1.0;
+  int flags = 0;   // bit 0 two_norm, bit 1 rel_change
+};
+
+__global__ void pack_new_p_kernel(int n, const int *__restrict__ idx, HaloFuse f, double *__restrict__ out) {
+  const PcgState *st = f.st;
+  if (st->done != 0) return;
+  const double gamma_new = f.buf3[0];
+  const double i_prod = (f.flags & 1) ? f.buf3[1] : f.buf3[0];
+  const double xx = f.buf3[2];
+  bool conv = (i_prod / st->bi_prod < st->eps);
+  if (conv && (f.flags & 2) && i_prod > 0.0) {
+    const double ratio = st->alpha * st->alpha * st->pp / xx;
+    if (ratio >= st->eps) conv = false;
+  }
+  const bool tiny_gamma = (gamma_new < DBL_MIN) && (-gamma_new < DBL_MIN);
+  if (conv || tiny_gamma) return;
+  const double beta = gamma_new / st->gamma_old;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int row = idx[i];
+    double z = f.r[row];
+    z *= f.zscale;
+    out[i] = beta * f.p_old[row] + z;
+  }
+}
+
 // y[rows[i]] += alpha * sum_k val[k] * xghost[col[k]]  over the offd block; with DOT the
 // per-block partial of sum_i (contribution_i * xlocal[rows[i]]) goes to slab component 0
 // (component 1 gets 0) so that <A p, p> can be completed after the diag pass.
@@ -372,12 +405,15 @@ static int build_plan_local(LocalWorld *W) {
 
 // ------------------------------------------------------------------- communication phases
 // v[r] has n_local owned entries followed by n_ghost ghost entries
-static int halo_exchange(int R, mk_dist_matrix **A, double **v, bool overlap) {
+static int halo_exchange(int R, mk_dist_matrix **A, double **v, bool overlap, const HaloFuse *fuse = nullptr) {
   Context &c = ctx();
   if (A[0]->comm == nullptr) return MK_OK;
   if (A[0]->comm->local) {
     for (int r = 0; r < R; r++)
-      if (A[r]->n_send) hipLaunchKernelGGL(pack_kernel, dim3(grid1(A[r]->n_send, 1024)), dim3(256), 0, c.stream, A[r]->n_send, A[r]->send_idx, v[r], A[r]->sendbuf);
+      if (A[r]->n_send) {
+        if (fuse && fuse[r].st) hipLaunchKernelGGL(pack_new_p_kernel, dim3(grid1(A[r]->n_send, 1024)), dim3(256), 0, c.stream, A[r]->n_send, A[r]->send_idx, fuse[r], A[r]->sendbuf);
+        else hipLaunchKernelGGL(pack_kernel, dim3(grid1(A[r]->n_send, 1024)), dim3(256), 0, c.stream, A[r]->n_send, A[r]->send_idx, v[r], A[r]->sendbuf);
+      }
     for (int r = 0; r < R; r++)
       for (int q = 0; q < R; q++)
         if (A[r]->recv_cnt[q])
@@ -392,7 +428,10 @@ static int halo_exchange(int R, mk_dist_matrix **A, double **v, bool overlap) {
     MK_HIP(hipEventRecord(cm->ev_ready, c.stream));
     MK_HIP(hipStreamWaitEvent(s, cm->ev_ready, 0));
   }
-  if (D->n_send) hipLaunchKernelGGL(pack_kernel, dim3(grid1(D->n_send, 1024)), dim3(256), 0, s, D->n_send, D->send_idx, v[0], D->sendbuf);
+  if (D->n_send) {
+    if (fuse && fuse[0].st) hipLaunchKernelGGL(pack_new_p_kernel, dim3(grid1(D->n_send, 1024)), dim3(256), 0, s, D->n_send, D->send_idx, fuse[0], D->sendbuf);
+    else hipLaunchKernelGGL(pack_kernel, dim3(grid1(D->n_send, 1024)), dim3(256), 0, s, D->n_send, D->send_idx, v[0], D->sendbuf);
+  }
   MK_NCCL(g_rccl.GroupStart());
   for (int q = 0; q < D->nranks; q++) {
     if (D->send_cnt[q]) MK_NCCL(g_rccl.Send(D->sendbuf + D->send_off[q], (size_t)D->send_cnt[q], ncclDouble, q, cm->p2p, s));
@@ -470,9 +509,10 @@ static __global__ void offd_resid_kernel(int nrows, const int *__restrict__ rows
 struct DistWork {
   double *r = nullptr, *p = nullptr, *s = nullptr, *slab1 = nullptr, *slab2 = nullptr, *buf = nullptr, *norms = nullptr;
   double *t = nullptr;   // fused step: off-rank part of A p over the rows that touch ghosts
+  double *p2 = nullptr;  // fused step: the other p buffer (K3 folded into the first sweep writes p' there)
   PcgState *state = nullptr;
   void release() {
-    dev_free(t);
+    dev_free(t); dev_free(p2);
     dev_free(r); dev_free(p); dev_free(s); dev_free(slab1); dev_free(slab2); dev_free(buf); dev_free(state); dev_free(norms);
   }
 };
@@ -728,9 +768,12 @@ int mk_dist_pcg_solve(int R, mk_pcg **solvers, mk_dist_matrix **A, mk_vector **b
   const bool rccl = A[0]->comm != nullptr && !A[0]->comm->local;
   const bool want_norms = S0->logging > 0 || S0->print_level > 0;
   std::vector<DistWork> W(R);
-  std::vector<double *> pv(R), xv(R), bufs(R);
-  std::vector<int> vb(R), nb1(R), nb2(R), fusedv(R, 0);
+  std::vector<double *> pv(R), xv(R), bufs(R), pold(R, nullptr);
+  std::vector<int> vb(R), nb1(R), nb2(R), fusedv(R, 0), pfuse(R, 0);
+  std::vector<double> zs(R, 1.0);
+  std::vector<HaloFuse> hf(R);
   static const int no_fused = getenv("MK_NO_FUSED_CG") ? atoi(getenv("MK_NO_FUSED_CG")) : 0;
+  static const int no_pfuse = getenv("MK_NO_FUSED_K3") ? atoi(getenv("MK_NO_FUSED_K3")) : 0;
   int rc = MK_OK;
   auto cleanup = [&]() { (void)hipDeviceSynchronize(); for (auto &w : W) w.release(); };
 #define MK_D(expr) do { rc = (expr); if (rc != MK_OK) { cleanup(); return rc; } } while (0)
@@ -754,6 +797,10 @@ int mk_dist_pcg_solve(int R, mk_pcg **solvers, mk_dist_matrix **A, mk_vector **b
     // and iteration instead of 90).  Decided per rank: both variants all-reduce the same 2 + 3 values.
     fusedv[r] = (D->diag.kernel == MK_SPMV_SWEEP) && !no_fused && D->n_local > 0;
     if (fusedv[r]) MK_D(dev_alloc(&W[r].t, (size_t)std::max(D->n_offd_rows, 1)));
+    // ... and fold K3 into the first sweep when 1/diag is one number (or there is no preconditioner)
+    zs[r] = 1.0;
+    pfuse[r] = fusedv[r] && !no_pfuse && (S0->precond != MK_PRECOND_JACOBI || sweep_uniform_diag(&D->diag, &zs[r]));
+    if (pfuse[r]) MK_D(dev_alloc(&W[r].p2, ne));
     solvers[r]->iterations = 0; solvers[r]->rel_res_norm = 0.0; solvers[r]->converged = 0; solvers[r]->breakdown = 0;
   }
   PcgState *hst = static_cast<PcgState *>(c.pinned);
@@ -784,15 +831,29 @@ int mk_dist_pcg_solve(int R, mk_pcg **solvers, mk_dist_matrix **A, mk_vector **b
 
   bool stop = zero_rhs;
   for (int it = 0; it < S0->max_iter && !stop; it++) {
-    MK_D(halo_exchange(R, A, pv.data(), rccl));                                  // on the communication stream over RCCL
+    // ranks with K3 folded into the first sweep: from the second iteration on p' = z + beta p is formed inside that
+    // sweep, into the other p buffer; its send rows are formed ahead by the pack kernel so the halo can start now
+    for (int r = 0; r < R; r++) {
+      hf[r] = HaloFuse();
+      if (pfuse[r] && it > 0) {
+        hf[r].r = W[r].r; hf[r].p_old = pv[r]; hf[r].buf3 = W[r].buf + 4; hf[r].st = W[r].state;
+        hf[r].zscale = zs[r]; hf[r].flags = (two_norm ? 1 : 0) | (rel_change ? 2 : 0);
+        pold[r] = pv[r];
+        pv[r] = (pv[r] == W[r].p) ? W[r].p2 : W[r].p;
+      }
+    }
+    MK_D(halo_exchange(R, A, pv.data(), rccl, hf.data()));                       // on the communication stream over RCCL
     for (int r = 0; r < R; r++) {                                                 // K1a: diag block, overlaps the halo
-      if (fusedv[r]) MK_D(launch_sweep_cg_dots(&A[r]->diag, W[r].p, W[r].slab1, W[r].state, &nb1[r]));
-      else MK_D(launch_spmv_dot(&A[r]->diag, W[r].p, W[r].s, W[r].slab1, &W[r].state->done, &nb1[r]));
+      if (pfuse[r] && it > 0)
+        MK_D(launch_sweep_cg_pdots(&A[r]->diag, W[r].r, pold[r], pv[r], zs[r], W[r].buf + 4, 1, 1, W[r].slab1, W[r].state, two_norm,
+                                   rel_change, W[r].norms, &nb1[r]));
+      else if (fusedv[r]) MK_D(launch_sweep_cg_dots(&A[r]->diag, pv[r], W[r].slab1, W[r].state, &nb1[r]));
+      else MK_D(launch_spmv_dot(&A[r]->diag, pv[r], W[r].s, W[r].slab1, &W[r].state->done, &nb1[r]));
     }
     for (int r = 0; r < R; r++) {                                                 // K1b: offd block once the ghosts are in
       MK_D(halo_wait(A[r], rccl));
-      if (fusedv[r]) MK_D(launch_offd_compact(A[r], W[r].p, W[r].t, W[r].slab1 + nb1[r], &W[r].state->done, &nb2[r]));
-      else MK_D(launch_offd<true>(A[r], W[r].p, W[r].s, 1.0, W[r].slab1 + nb1[r], &W[r].state->done, &nb2[r]));
+      if (fusedv[r]) MK_D(launch_offd_compact(A[r], pv[r], W[r].t, W[r].slab1 + nb1[r], &W[r].state->done, &nb2[r]));
+      else MK_D(launch_offd<true>(A[r], pv[r], W[r].s, 1.0, W[r].slab1 + nb1[r], &W[r].state->done, &nb2[r]));
       hipLaunchKernelGGL((finalize_slab_kernel<2>), dim3(1), dim3(kVecThreads), 0, c.stream, W[r].slab1, nb1[r] + nb2[r], W[r].buf);
     }
     MK_D(all_reduce(R, A, bufs.data(), 2));                                       // <s,p>, <p,p>
@@ -804,22 +865,24 @@ int mk_dist_pcg_solve(int R, mk_pcg **solvers, mk_dist_matrix **A, mk_vector **b
         if (A[r]->n_offd_rows > 0)
           hipLaunchKernelGGL(offd_resid_kernel, dim3(grid1(A[r]->n_offd_rows, 1024)), dim3(256), 0, c.stream, A[r]->n_offd_rows,
                              A[r]->offd_rows, W[r].t, W[r].r, W[r].buf, W[r].state);
-        MK_D(launch_sweep_cg_resid_x(&A[r]->diag, W[r].p, W[r].r, x[r]->d, S0->precond == MK_PRECOND_JACOBI ? A[r]->diag.dinv : nullptr,
+        MK_D(launch_sweep_cg_resid_x(&A[r]->diag, pv[r], W[r].r, x[r]->d, S0->precond == MK_PRECOND_JACOBI ? A[r]->diag.dinv : nullptr,
                                      W[r].buf, 1, 1, W[r].slab2, W[r].state, &nbk2));
       } else if (S0->precond == MK_PRECOND_JACOBI)
-        hipLaunchKernelGGL((pcg_update_xr_kernel<true>), dim3(vb[r]), dim3(kVecThreads), 0, c.stream, nl, W[r].p, W[r].s, A[r]->diag.dinv, x[r]->d, W[r].r, W[r].buf, 1, 1, W[r].slab2, W[r].state);
+        hipLaunchKernelGGL((pcg_update_xr_kernel<true>), dim3(vb[r]), dim3(kVecThreads), 0, c.stream, nl, pv[r], W[r].s, A[r]->diag.dinv, x[r]->d, W[r].r, W[r].buf, 1, 1, W[r].slab2, W[r].state);
       else
-        hipLaunchKernelGGL((pcg_update_xr_kernel<false>), dim3(vb[r]), dim3(kVecThreads), 0, c.stream, nl, W[r].p, W[r].s, (const double *)nullptr, x[r]->d, W[r].r, W[r].buf, 1, 1, W[r].slab2, W[r].state);
+        hipLaunchKernelGGL((pcg_update_xr_kernel<false>), dim3(vb[r]), dim3(kVecThreads), 0, c.stream, nl, pv[r], W[r].s, (const double *)nullptr, x[r]->d, W[r].r, W[r].buf, 1, 1, W[r].slab2, W[r].state);
       hipLaunchKernelGGL((finalize_slab_kernel<3>), dim3(1), dim3(kVecThreads), 0, c.stream, W[r].slab2, nbk2, buf3);
       bufs[r] = buf3;
     }
     MK_D(all_reduce(R, A, bufs.data(), 3));                                       // <r,z>, <r,r>, <x,x>
     for (int r = 0; r < R; r++) {
       const int64_t nl = A[r]->n_local;
+      bufs[r] = W[r].buf;
+      if (pfuse[r]) continue;   // K3 rides in the next iteration's first sweep
       if (S0->precond == MK_PRECOND_JACOBI)
-        hipLaunchKernelGGL((pcg_update_p_kernel<true>), dim3(vb[r]), dim3(kVecThreads), 0, c.stream, nl, W[r].r, A[r]->diag.dinv, W[r].p, W[r].buf + 4, 1, 1, two_norm, rel_change, W[r].state, W[r].norms);
+        hipLaunchKernelGGL((pcg_update_p_kernel<true>), dim3(vb[r]), dim3(kVecThreads), 0, c.stream, nl, W[r].r, A[r]->diag.dinv, pv[r], W[r].buf + 4, 1, 1, two_norm, rel_change, W[r].state, W[r].norms);
       else
-        hipLaunchKernelGGL((pcg_update_p_kernel<false>), dim3(vb[r]), dim3(kVecThreads), 0, c.stream, nl, W[r].r, (const double *)nullptr, W[r].p, W[r].buf + 4, 1, 1, two_norm, rel_change, W[r].state, W[r].norms);
+        hipLaunchKernelGGL((pcg_update_p_kernel<false>), dim3(vb[r]), dim3(kVecThreads), 0, c.stream, nl, W[r].r, (const double *)nullptr, pv[r], W[r].buf + 4, 1, 1, two_norm, rel_change, W[r].state, W[r].norms);
       bufs[r] = W[r].buf;
     }
     if ((it + 1) % S0->check_every == 0) {
@@ -828,6 +891,9 @@ int mk_dist_pcg_solve(int R, mk_pcg **solvers, mk_dist_matrix **A, mk_vector **b
       if (hst[0].done != 0) stop = true;   // the same on every rank: it derives from all-reduced values only
     }
   }
+  for (int r = 0; r < R; r++)   // the test the next iteration's first sweep would have made (K3's prologue; n = 0: no p update)
+    if (pfuse[r] && S0->max_iter > 0 && !zero_rhs)
+      hipLaunchKernelGGL((pcg_update_p_kernel<false>), dim3(1), dim3(kVecThreads), 0, c.stream, (int64_t)0, W[r].r, (const double *)nullptr, pv[r], W[r].buf + 4, 1, 1, two_norm, rel_change, W[r].state, W[r].norms);
   MK_DH(hipGetLastError());
   MK_DH(hipMemcpyAsync(&hst[0], W[0].state, sizeof(PcgState), hipMemcpyDeviceToHost, c.stream));
   MK_DH(hipDeviceSynchronize());
