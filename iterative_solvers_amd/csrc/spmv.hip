@@ -224,8 +224,11 @@ static int plan_sweep(mk_matrix *A, const std::vector<int> &tab, const std::vect
       const int o = std::abs(off_of(base, u));
       if (2 * o > maxabs) lo = std::min(lo, o);
     }
-    const int P = (lo + hi) / 2;
-    if (P < 2 || (P & 1) || ((lo + hi) & 1)) return MK_OK;
+    // any even stride near the centre will do (b absorbs the difference); a grid gives lo + hi = 2 * plane exactly,
+    // and an odd plane cannot be used: a lane's two rows would straddle planes
+    if (lo == hi && (lo & 1)) return MK_OK;
+    const int P = ((lo + hi) / 2) & ~1;
+    if (P < 2) return MK_OK;
     S.P = P;
     for (int u = 0; u < len; u++) {
       const int o = off_of(base, u);

@@ -287,6 +287,56 @@ def test_spmv_pattern_and_sweep_ragged_sizes(n, hb):
         assert np.allclose(xj.get(), oj["x"], rtol=1e-12, atol=0)
 
 
+@pytest.mark.parametrize("seed,P,K,nbase", [(1, 640, 9, 9), (2, 1024, 5, 14), (3, 96, 40, 6), (4, 2048, 12, 12)])
+def test_spmv_sweep_kernel_random_patterns(seed, P, K, nbase):
+    """not a grid: a random base pattern with offsets a*P + b (a in {-1,0,1}, unsymmetric, unsorted), every row a
+    random sub-list of it chosen among ~20 masks, row-dependent sub-lists at the matrix ends.  Pattern and sweep
+    kernels must reproduce the serial reference bit for bit (same pairs, same order)."""
+    rng = np.random.default_rng(seed)
+    n = P * K
+    bmax = min(P // 2 - 1, 300)
+    offs = []
+    while len(offs) < nbase:
+        o = int(rng.integers(-1, 2)) * P + int(rng.integers(-bmax, bmax + 1))
+        if o not in offs:
+            offs.append(o)
+    if 0 not in offs:
+        offs[int(rng.integers(0, nbase))] = 0            # keep a diagonal (Jacobi modes)
+    offs = np.array(offs)
+    vals = rng.normal(size=nbase)
+    vals[offs == 0] = 4.0 + nbase
+    masks = [np.ones(nbase, bool)] + [rng.random(nbase) < 0.7 for _ in range(19)]
+    for m in masks:
+        m[offs == 0] = True
+    which = rng.integers(0, len(masks), n)
+    which[rng.random(n) < 0.6] = 0                        # most rows carry the full pattern
+    rows_c, rows_v = [], []
+    for i in range(n):
+        keep = masks[which[i]] & (i + offs >= 0) & (i + offs < n)
+        rows_c.append(i + offs[keep])
+        rows_v.append(vals[keep])
+    lens = np.array([c.size for c in rows_c])
+    rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    ci = np.concatenate(rows_c).astype(np.int32)
+    v = np.concatenate(rows_v)
+    A = mk.Matrix.from_csr(n, n, rp, ci, v)
+    assert A.info().value_patterns > 0
+    xh = rng.normal(size=n)
+    ref = oracle.csr_spmv(rp, ci, v, xh)
+    for k in (mk.SPMV_PATTERN, mk.SPMV_SWEEP):
+        A.set_spmv_kernel(k)
+        x, y = mk.Vector(n, values=xh), mk.Vector(n, fill=9.0)
+        A.spmv(x, y)
+        assert np.array_equal(y.get(), ref), k
+        _check_spmv(A, rp, ci, v, n, n, rng, alpha=1.25, beta=-0.5)
+        oj = oracle.jacobi(rp, ci, v, np.ones(n), tol=1e-30, maxit=8, check_every=4)
+        J = mk.Jacobi(max_iter=8, tol=1e-30, check_every=4)
+        b, xj = mk.Vector(n, fill=1.0), mk.Vector(n, fill=0.0)
+        J.setup(A, b, xj)
+        J.solve(A, b, xj)
+        assert np.allclose(xj.get(), oj["x"], rtol=1e-12, atol=0), k
+
+
 def test_spmv_sweep_kernel_eligibility():
     rp, ci, v = oracle.stencil_csr(7, 31, 29, 3)           # plane of 899 rows: odd stride, a lane's two rows would straddle planes
     n = rp.size - 1
