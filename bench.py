@@ -160,7 +160,12 @@ def main():
         "roofline": {"bound": "hbm", "kernel": "spmv+dot (K1, %s kernel)" % kname, "achieved": round(achieved, 1),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "bytes_per_launch": spmv_bytes, "avg_launch_ms": round(spmv_ms, 5),
-                     "csr_model_bytes": csr_bytes, "csr_model_GBps": round(csr_bytes / (spmv_ms * 1e-3) / 1e9, 1)},
+                     "bytes_model": ("18 B/row: 2 B pattern id + 8 B x + 8 B y (what the pattern/sweep kernels read and write)"
+                                     if info.kernel in (4, 5) else "SURVEY 8(d): 12 nnz + 20 n + 4"),
+                     # the north star counts values + column indices + row pointers + x/y; priced that
+                     # way a launch that reads 2 B of matrix data per row exceeds the peak by construction
+                     "csr_model_bytes": csr_bytes, "csr_model_GBps": round(csr_bytes / (spmv_ms * 1e-3) / 1e9, 1),
+                     "csr_model_frac": round(csr_bytes / (spmv_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
         "final_rel_res_norm": res["rel_res_norm"],
     }
     del A, b, s
