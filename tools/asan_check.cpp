@@ -1,0 +1,116 @@
+// Host-side AddressSanitizer pass over the library: the .hip sources are compiled with
+// `-Xarch_host -fsanitize=address` into this one executable (tools/asan_check.sh) and the main entry points are
+// driven once through the C ABI.  Checks host heap use only; device code is not instrumented.
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "../include/mk_krylov.h"
+
+#define CK(x) do { int rc_ = (x); if (rc_ != 0) { fprintf(stderr, "%s:%d: %s -> %d (%s)\n", __FILE__, __LINE__, #x, rc_, mk_last_error_string()); exit(1); } } while (0)
+
+static void one_matrix(int nx, int ny, int nz) {
+  const int64_t n = (int64_t)nx * ny * nz;
+  mk_matrix *A = nullptr;
+  CK(mk_matrix_generate_stencil(7, nx, ny, nz, 0, n, &A));
+  mk_vector *b = nullptr, *x = nullptr;
+  CK(mk_vector_create(n, &b)); CK(mk_vector_create(n, &x));
+  CK(mk_vector_fill(b, 1.0));
+  for (int kernel = 0; kernel <= 5; kernel++) {
+    if (mk_matrix_set_spmv_kernel(A, kernel, 0) != 0) continue;
+    CK(mk_vector_fill(x, 0.0));
+    mk_pcg *S = nullptr;
+    CK(mk_pcg_create(&S)); CK(mk_pcg_set_max_iter(S, 40)); CK(mk_pcg_set_tol(S, 1e-9)); CK(mk_pcg_set_logging(S, 1));
+    CK(mk_pcg_setup(S, A, b, x)); CK(mk_pcg_solve(S, A, b, x));
+    long long it = 0; CK(mk_pcg_get_num_iterations(S, &it));
+    std::vector<double> hist(64);
+    mk_pcg_get_residual_history(S, hist.data(), 64);
+    printf("  kernel %d: pcg %lld iterations\n", kernel, it);
+    CK(mk_pcg_destroy(S));
+  }
+  CK(mk_matrix_set_spmv_kernel(A, 0, 0));
+  { mk_bicgstab *S; CK(mk_bicgstab_create(&S)); CK(mk_bicgstab_set_max_iter(S, 20)); CK(mk_bicgstab_set_logging(S, 1)); CK(mk_vector_fill(x, 0.0));
+    CK(mk_bicgstab_setup(S, A, b, x)); CK(mk_bicgstab_solve(S, A, b, x)); CK(mk_bicgstab_destroy(S)); }
+  { mk_cgnr *S; CK(mk_cgnr_create(&S)); CK(mk_cgnr_set_max_iter(S, 20)); CK(mk_cgnr_set_logging(S, 1)); CK(mk_vector_fill(x, 0.0));
+    CK(mk_cgnr_setup(S, A, b, x)); CK(mk_cgnr_solve(S, A, b, x)); CK(mk_cgnr_destroy(S)); }
+  { mk_gmres *S; CK(mk_gmres_create(&S)); CK(mk_gmres_set_max_iter(S, 45)); CK(mk_gmres_set_logging(S, 1)); CK(mk_vector_fill(x, 0.0));
+    CK(mk_gmres_setup(S, A, b, x)); CK(mk_gmres_solve(S, A, b, x)); CK(mk_gmres_destroy(S)); }
+  { mk_jacobi *S; CK(mk_jacobi_create(&S)); CK(mk_jacobi_set_max_iter(S, 30)); CK(mk_vector_fill(x, 0.0));
+    CK(mk_jacobi_setup(S, A, b, x)); CK(mk_jacobi_solve(S, A, b, x)); CK(mk_jacobi_destroy(S)); }
+  SparseMatrixCSR csr = {};
+  CK(mk_matrix_get_csr(A, &csr));
+  mk_matrix *B = nullptr;
+  CK(mk_matrix_from_csr(&csr, &B));
+  free(csr.row_pointers); free(csr.column_indices); free(csr.values);
+  CK(mk_matrix_destroy(B));
+  CK(mk_vector_destroy(b)); CK(mk_vector_destroy(x)); CK(mk_matrix_destroy(A));
+}
+
+static void rmat() {
+  mk_coo *coo = nullptr;
+  CK(mk_coo_generate_rmat(14, 1u << 18, 7, 0.57, 0.19, 0.19, &coo));
+  mk_matrix *A = nullptr;
+  CK(mk_matrix_from_device_coo(coo, &A));
+  CK(mk_coo_destroy(coo));
+  mk_matrix_info info; CK(mk_matrix_get_info(A, &info));
+  mk_vector *x, *y; CK(mk_vector_create(info.ncols, &x)); CK(mk_vector_create(info.nrows, &y)); CK(mk_vector_fill(x, 1.0));
+  for (int kernel = 0; kernel <= 3; kernel++) { if (mk_matrix_set_spmv_kernel(A, kernel, 0) == 0) CK(mk_spmv(A, 1.0, x, 0.0, y)); }
+  double a, b2; CK(mk_spmv_dot(A, x, y, &a, &b2));
+  CK(mk_vector_destroy(x)); CK(mk_vector_destroy(y)); CK(mk_matrix_destroy(A));
+}
+
+static void world(int nx, int ny, int nz, int R, bool rccl, int precond) {
+  const int64_t n = (int64_t)nx * ny * nz;
+  std::vector<int64_t> rs(R + 1);
+  for (int r = 0; r <= R; r++) rs[r] = (int64_t)nx * ny * ((int64_t)nz * r / R);
+  std::vector<mk_comm *> comms(R);
+  if (rccl) {
+    char id[256]; CK(mk_comm_get_unique_id(id)); CK(mk_comm_create(id, 1, 0, &comms[0])); CK(mk_comm_self_test(comms[0]));
+  } else CK(mk_comm_create_local(R, comms.data()));
+  std::vector<mk_dist_matrix *> D(R);
+  std::vector<mk_vector *> b(R), x(R);
+  std::vector<mk_pcg *> S(R);
+  std::vector<mk_jacobi *> J(R);
+  for (int r = 0; r < R; r++) {
+    mk_matrix *blk = nullptr;
+    CK(mk_matrix_generate_stencil(7, nx, ny, nz, rs[r], rs[r + 1], &blk));
+    CK(mk_dist_matrix_create(blk, n, rs.data(), comms[r], &D[r]));
+  }
+  for (int r = 0; r < R; r++) {
+    CK(mk_dist_vector_create(D[r], &b[r])); CK(mk_dist_vector_create(D[r], &x[r]));
+    CK(mk_vector_fill(b[r], 1.0)); CK(mk_vector_fill(x[r], 0.0));
+    CK(mk_pcg_create(&S[r])); CK(mk_pcg_set_max_iter(S[r], 60)); CK(mk_pcg_set_tol(S[r], 1e-9)); CK(mk_pcg_set_logging(S[r], 1));
+    CK(mk_pcg_set_precond(S[r], precond));
+    CK(mk_jacobi_create(&J[r])); CK(mk_jacobi_set_max_iter(J[r], 25));
+  }
+  CK(mk_dist_spmv(R, D.data(), b.data(), x.data()));
+  for (int r = 0; r < R; r++) CK(mk_vector_fill(x[r], 0.0));
+  CK(mk_dist_pcg_solve(R, S.data(), D.data(), b.data(), x.data()));
+  long long it = 0; CK(mk_pcg_get_num_iterations(S[0], &it));
+  printf("  world of %d (%s, precond %d): pcg %lld iterations\n", R, rccl ? "rccl" : "local", precond, it);
+  for (int r = 0; r < R; r++) CK(mk_vector_fill(x[r], 0.0));
+  CK(mk_dist_jacobi_solve(R, J.data(), D.data(), b.data(), x.data()));
+  for (int r = 0; r < R; r++) {
+    CK(mk_pcg_destroy(S[r])); CK(mk_jacobi_destroy(J[r])); CK(mk_vector_destroy(b[r])); CK(mk_vector_destroy(x[r]));
+    CK(mk_dist_matrix_destroy(D[r]));
+  }
+  for (int r = 0; r < R; r++) CK(mk_comm_destroy(comms[r]));
+}
+
+int main() {
+  CK(mk_init(0));
+  printf("single matrix\n");
+  one_matrix(64, 64, 64);
+  one_matrix(19, 11, 13);
+  one_matrix(128, 128, 96);
+  printf("rmat\n");
+  rmat();
+  printf("row blocks\n");
+  world(64, 64, 64, 4, false, 0);
+  world(128, 128, 128, 8, false, 0);
+  world(128, 128, 128, 8, false, 1);
+  world(24, 20, 9, 3, false, 0);
+  world(64, 64, 32, 1, true, 0);
+  CK(mk_finalize());
+  printf("asan_check: done\n");
+  return 0;
+}

@@ -52,5 +52,6 @@ def dist(it):
 
 
 ms2 = timed(dist)
+del As, bs, xs, comms   # release device objects before the interpreter (and a profiler's exit hooks) tear down
 print(f"{nx}x{ny}x{nz}: single matrix {ms1:.3f} ms/iteration; {world} local ranks {ms2:.3f} ms/iteration "
       f"({ms2 / world:.3f} ms per rank-iteration)", flush=True)
