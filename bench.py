@@ -76,14 +76,15 @@ def main():
 
     import torch
     import torch.distributed as dist
-    if world > 1:
+    force_dist = bool(os.environ.get("MK_BENCH_FORCE_DIST"))   # rehearsal: the row-block path with a world of one
+    if world > 1 or force_dist:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         torch.cuda.set_device(local_rank)
 
     import iterative_solvers_amd as mk
     mk.init(local_rank)
 
-    if world > 1:
+    if world > 1 or force_dist:
         from iterative_solvers_amd import distributed as mkd
         return mkd.bench_main(args, rank, local_rank, world, WORKLOADS, HBM_PEAK_GBS)
 

@@ -272,6 +272,8 @@ int mk_dist_matrix_get_info(const mk_dist_matrix *A, int64_t *n_local, int64_t *
                             int64_t *nnz_diag, int64_t *nnz_offd, int *n_neighbors);
 /* mk_matrix_set_spmv_kernel for the diag block (the off-rank block has its own small kernel) */
 int mk_dist_matrix_set_spmv_kernel(mk_dist_matrix *A, int kernel, int lanes_per_row);
+/* mk_matrix_get_info of the diag block (which SpMV kernel the selector took, pattern counts) */
+int mk_dist_matrix_get_diag_info(mk_dist_matrix *A, mk_matrix_info *info);
 /* vector of n_local owned entries with room for the ghost entries behind them */
 int mk_dist_vector_create(const mk_dist_matrix *A, mk_vector **v);
 /* nranks_here = 1 over RCCL, = world size for a local world (arrays in rank order) */

@@ -72,7 +72,7 @@ EXPORTS = [
     "mk_jacobi_get_final_relative_residual_norm", "mk_jacobi_get_converged", "mk_jacobi_destroy",
     "mk_partition_rows",
     "mk_comm_get_unique_id", "mk_comm_create", "mk_comm_create_local", "mk_comm_self_test", "mk_comm_destroy",
-    "mk_dist_matrix_create", "mk_dist_matrix_destroy", "mk_dist_matrix_get_info", "mk_dist_matrix_set_spmv_kernel",
+    "mk_dist_matrix_create", "mk_dist_matrix_destroy", "mk_dist_matrix_get_info", "mk_dist_matrix_get_diag_info", "mk_dist_matrix_set_spmv_kernel",
     "mk_dist_vector_create", "mk_dist_spmv", "mk_dist_pcg_solve", "mk_dist_jacobi_solve",
 ]
 
@@ -103,6 +103,7 @@ def load():
         "mk_matrix_from_device_coo": [P, C.POINTER(P)],
         "mk_matrix_destroy": [P], "mk_matrix_get_csr": [P, C.POINTER(CSR)],
         "mk_matrix_get_info": [P, C.POINTER(MatrixInfo)],
+        "mk_dist_matrix_get_diag_info": [P, C.POINTER(MatrixInfo)],
         "mk_matrix_set_spmv_kernel": [P, C.c_int, C.c_int],
         "mk_matrix_generate_stencil": [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.POINTER(P)],
         "mk_matrix_generate_banded": [C.c_int64, C.c_int, C.c_int64, C.c_int64, C.POINTER(P)],

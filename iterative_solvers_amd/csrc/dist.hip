@@ -703,6 +703,11 @@ int mk_dist_matrix_set_spmv_kernel(mk_dist_matrix *D, int kernel, int lanes_per_
   return mk_matrix_set_spmv_kernel(&D->diag, kernel, lanes_per_row);
 }
 
+int mk_dist_matrix_get_diag_info(mk_dist_matrix *D, mk_matrix_info *info) {
+  if (!D) return fail(MK_ERR_INVALID, "mk_dist_matrix_get_diag_info: null matrix");
+  return mk_matrix_get_info(&D->diag, info);
+}
+
 int mk_dist_vector_create(const mk_dist_matrix *D, mk_vector **v) {
   MK_REQUIRE_INIT();
   if (!D || !v) return fail(MK_ERR_INVALID, "mk_dist_vector_create: null argument");

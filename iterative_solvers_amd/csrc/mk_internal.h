@@ -248,10 +248,20 @@ __device__ __forceinline__ void block_sum(double (&v)[NP], double *smem /* NP*(T
 template <int NP, int THREADS>
 __device__ __forceinline__ void reduce_slab(const double *slab, int nblocks, int stride, double (&out)[NP], double *smem) {
 #pragma unroll
-  for (int k = 0; k < NP; k++) {
-    double s = 0.0;
-    for (int i = threadIdx.x; i < nblocks; i += THREADS) s += slab[k * stride + i];
-    out[k] = s;
+  for (int k = 0; k < NP; k++) out[k] = 0.0;
+  // four loads per component in flight (a serial chain of dependent loads made the one-block finalize kernel of
+  // the row-block solver 7 us long); added in index order, so the bits do not depend on the batching
+  for (int i0 = threadIdx.x; i0 < nblocks; i0 += 4 * THREADS) {
+    double t[NP][4];
+#pragma unroll
+    for (int k = 0; k < NP; k++)
+#pragma unroll
+      for (int u = 0; u < 4; u++) t[k][u] = slab[k * stride + min(i0 + u * THREADS, nblocks - 1)];
+#pragma unroll
+    for (int k = 0; k < NP; k++)
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+        if (i0 + u * THREADS < nblocks) out[k] += t[k][u];
   }
   block_sum<NP, THREADS>(out, smem);
 }
