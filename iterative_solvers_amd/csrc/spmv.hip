@@ -1337,6 +1337,19 @@ static int launch_sweep(const mk_matrix *A, double alpha, const double *x, doubl
   const int64_t target = (int64_t)c.num_cus * per_cu;
   // two rounds of resident blocks (measured at 512^3: 1 segment 647 us, 3 segments 542 us, 6 segments 540 us)
   int nseg = env_nseg > 0 ? env_nseg : (int)std::max<int64_t>(1, (2 * target + S.ncp - 1) / S.ncp);
+  // ... unless the grid can be exactly one round with 8 waves on every CU (16 for the 1024-thread variant): then all
+  // blocks walk the same plane front and no CU holds a second segment.  Measured CG iteration, ns per row,
+  // exact fit against the best of the multi-round counts: 512^3 0.0124 / 0.0133, 512x512x64 0.0130 / 0.0140,
+  // 256^3 0.0135 / 0.0148.  A grid that misses the fit (384^3: 144 chunks per plane) keeps the rule above:
+  // 288 blocks on 256 CUs was the slowest choice of all.
+  static const int no_fit = getenv("MK_SWEEP_NO_FIT") ? atoi(getenv("MK_SWEEP_NO_FIT")) : 0;
+  // Only the two CG sweeps (3 and 5 streams each) gain; SpMV+dot (x in, y out) measured 4-10 % SLOWER with the fit
+  // (512^3 490 against 469 us, 27-point 256^3 159 against 144 us, banded 2^26 280 against 259 us).
+  if (env_nseg <= 0 && !no_fit && (MODE == 4 || MODE == 5)) {
+    const int64_t fit = (int64_t)c.num_cus * std::max(1, 1024 / S.C);
+    const int64_t k = fit / S.ncp;
+    if (k >= 1 && k * S.ncp * 10 >= fit * 9 && S.K / k >= 8) nseg = (int)k;
+  }
   nseg = std::min(nseg, std::max(1, S.K / 8));
   nseg = std::max(1, std::min(nseg, S.K));
   while ((int64_t)S.ncp * nseg > kSlabStride - 8 && nseg > 1) nseg--;
