@@ -211,7 +211,8 @@ def test_spmv_pattern_kernel_value_edge_cases():
 
 
 @pytest.mark.parametrize("kind,dims", [(7, (64, 64, 40)), (7, (30, 22, 10)), (27, (16, 18, 9)), (27, (40, 40, 6)),
-                                       (5, (128, 96, 1)), (7, (512, 4, 5)), (7, (24, 16, 33))])
+                                       (5, (128, 96, 1)), (7, (512, 4, 5)), (7, (24, 16, 33)),
+                                       (7, (640, 4, 5)), (7, (1024, 3, 4)), (27, (700, 3, 3))])   # wide rows: 2048-row chunks
 def test_spmv_sweep_kernel(kind, dims):
     """grid operators whose rows are sub-lists of one pattern: plane-by-plane sweep with the x window in
     LDS.  Same (column, value) pairs in the same order as the CSR arrays -> the serial reference's bits."""
@@ -560,7 +561,7 @@ def test_pcg_3d_jacobi_precond_random_diag():
         assert np.linalg.norm(x.get() - o["x"]) <= 1e-6 * np.linalg.norm(o["x"])
 
 
-@pytest.mark.parametrize("kind,dims", [(5, (96, 96, 1)), (7, (32, 16, 20)), (27, (16, 18, 9)), (7, (64, 32, 9))])
+@pytest.mark.parametrize("kind,dims", [(5, (96, 96, 1)), (7, (32, 16, 20)), (27, (16, 18, 9)), (7, (64, 32, 9)), (7, (640, 4, 6))])
 @pytest.mark.parametrize("precond", [0, 1])
 @pytest.mark.parametrize("rel_change", [0, 1])
 def test_pcg_fused_sweep_step_matches_oracle(kind, dims, precond, rel_change):
