@@ -148,18 +148,18 @@ int mk_pcg_solve(mk_pcg *S, const mk_matrix *A, const mk_vector *b, mk_vector *x
       MK_TRY(launch_sweep_cg_resid_x(A, pcur, S->r, x->d, dinv, S->slab1, nb1, kSlabStride, S->slab2, S->state, &nb2));
       if (!fuse_p) {
         if (dinv)
-          hipLaunchKernelGGL((pcg_update_p_kernel<true>), dim3(vb), dim3(kVecThreads), 0, c.stream, n, S->r, dinv, pcur, S->slab2, nb2, kSlabStride, S->two_norm, S->rel_change, S->state, S->norms);
+          hipLaunchKernelGGL((pcg_update_p_kernel<true>), dim3(vb), dim3(kVecThreads), 0, c.stream, n, S->r, dinv, pcur, S->slab2, nb2, kSlabStride, S->two_norm, S->rel_change, S->state, S->norms, (int)nt_rows(n));
         else
-          hipLaunchKernelGGL((pcg_update_p_kernel<false>), dim3(vb), dim3(kVecThreads), 0, c.stream, n, S->r, dinv, pcur, S->slab2, nb2, kSlabStride, S->two_norm, S->rel_change, S->state, S->norms);
+          hipLaunchKernelGGL((pcg_update_p_kernel<false>), dim3(vb), dim3(kVecThreads), 0, c.stream, n, S->r, dinv, pcur, S->slab2, nb2, kSlabStride, S->two_norm, S->rel_change, S->state, S->norms, (int)nt_rows(n));
       }
     } else {
     MK_TRY(launch_spmv_dot(A, S->p, S->s, S->slab1, &S->state->done, &nb1));
     if (dinv) {
-      hipLaunchKernelGGL((pcg_update_xr_kernel<true>), dim3(vb), dim3(kVecThreads), 0, c.stream, n, S->p, S->s, dinv, x->d, S->r, S->slab1, nb1, kSlabStride, S->slab2, S->state);
-      hipLaunchKernelGGL((pcg_update_p_kernel<true>), dim3(vb), dim3(kVecThreads), 0, c.stream, n, S->r, dinv, S->p, S->slab2, vb, kSlabStride, S->two_norm, S->rel_change, S->state, S->norms);
+      hipLaunchKernelGGL((pcg_update_xr_kernel<true>), dim3(vb), dim3(kVecThreads), 0, c.stream, n, S->p, S->s, dinv, x->d, S->r, S->slab1, nb1, kSlabStride, S->slab2, S->state, (int)nt_rows(n));
+      hipLaunchKernelGGL((pcg_update_p_kernel<true>), dim3(vb), dim3(kVecThreads), 0, c.stream, n, S->r, dinv, S->p, S->slab2, vb, kSlabStride, S->two_norm, S->rel_change, S->state, S->norms, (int)nt_rows(n));
     } else {
-      hipLaunchKernelGGL((pcg_update_xr_kernel<false>), dim3(vb), dim3(kVecThreads), 0, c.stream, n, S->p, S->s, dinv, x->d, S->r, S->slab1, nb1, kSlabStride, S->slab2, S->state);
-      hipLaunchKernelGGL((pcg_update_p_kernel<false>), dim3(vb), dim3(kVecThreads), 0, c.stream, n, S->r, dinv, S->p, S->slab2, vb, kSlabStride, S->two_norm, S->rel_change, S->state, S->norms);
+      hipLaunchKernelGGL((pcg_update_xr_kernel<false>), dim3(vb), dim3(kVecThreads), 0, c.stream, n, S->p, S->s, dinv, x->d, S->r, S->slab1, nb1, kSlabStride, S->slab2, S->state, (int)nt_rows(n));
+      hipLaunchKernelGGL((pcg_update_p_kernel<false>), dim3(vb), dim3(kVecThreads), 0, c.stream, n, S->r, dinv, S->p, S->slab2, vb, kSlabStride, S->two_norm, S->rel_change, S->state, S->norms, (int)nt_rows(n));
     }
     }
     if ((it + 1) % S->check_every == 0) {
@@ -178,7 +178,7 @@ int mk_pcg_solve(mk_pcg *S, const mk_matrix *A, const mk_vector *b, mk_vector *x
     }
   }
   if (fuse_p && S->max_iter > 0)   // the test that the next step's first kernel would have made (K3's prologue; n = 0: no p update)
-    hipLaunchKernelGGL((pcg_update_p_kernel<false>), dim3(1), dim3(kVecThreads), 0, c.stream, (int64_t)0, S->r, (const double *)nullptr, pcur, S->slab2, nb2, kSlabStride, S->two_norm, S->rel_change, S->state, S->norms);
+    hipLaunchKernelGGL((pcg_update_p_kernel<false>), dim3(1), dim3(kVecThreads), 0, c.stream, (int64_t)0, S->r, (const double *)nullptr, pcur, S->slab2, nb2, kSlabStride, S->two_norm, S->rel_change, S->state, S->norms, 0);
   MK_HIP(hipGetLastError());
   MK_HIP(hipMemcpyAsync(&hst[0], S->state, sizeof(PcgState), hipMemcpyDeviceToHost, c.stream));
   MK_HIP(hipStreamSynchronize(c.stream));

@@ -586,7 +586,7 @@ __global__ __launch_bounds__(kThreads) void spmv_stream_kernel(
 #pragma unroll
     for (int i = 0; i < NI; i++) {
       const int k = ib_ + (tid + i * kThreads) * 4;
-      if (k < ce_) ri[i] = *reinterpret_cast<const i4_t *>(col + k);
+      if (k < ce_) ri[i] = NT ? __builtin_nontemporal_load(reinterpret_cast<const i4_t *>(col + k)) : *reinterpret_cast<const i4_t *>(col + k);
     }
     (void)ib_;
   };
@@ -613,7 +613,7 @@ __global__ __launch_bounds__(kThreads) void spmv_stream_kernel(
     const bool have_row = row < r1;
     int b = 0, e = 0, pid = 0;
     if (have_row) { b = rowptr[row] - cb; e = rowptr[row + 1] - cb; }
-    if (COMP && have_row) pid = pat[row];
+    if (COMP && have_row) pid = NT ? __builtin_nontemporal_load(pat + row) : pat[row];
     __syncthreads();
     const double *sv = sval + (cb - vb);
     const int *sc = COMP ? scol + pid * (pml + 1) + 1 - b : scol + (cb - ib);   // sc[j]: column (or column - row) of entry j
@@ -672,17 +672,19 @@ __global__ __launch_bounds__(kThreads) void spmv_stream_kernel(
       }
     }
     if (g == 0 && have_row) {
+      double yv;
       if (MODE == 0) {
-        y[row] = (beta == 0.0) ? alpha * sum : alpha * sum + beta * yold;
+        yv = (beta == 0.0) ? alpha * sum : alpha * sum + beta * yold;
       } else if (MODE == 2) {
         const double res = rhs_r - sum;
-        y[row] = xr + res / dv;
+        yv = xr + res / dv;
         acc_yx += res * res;
       } else {
-        y[row] = sum;
+        yv = sum;
         acc_yx += sum * xr;
         acc_xx += xr * xr;
       }
+      if (NT) __builtin_nontemporal_store(yv, y + row); else y[row] = yv;
     }
     __syncthreads();
     chunk = next; cb = ncb; ce = nce; r0 = nr0; r1 = nr1;
@@ -1029,7 +1031,25 @@ static int launch_pattern(const mk_matrix *A, double alpha, const double *x, dou
 // kept ~7 x 8 B per row in flight in registers and was bound by latency x register file, here one
 // 8-byte stream per row feeds LDS and HBM sees x once.  Rows and entries are summed in the order
 // of the CSR arrays (a sub-list keeps the base's order) -> bitwise identical to the serial reference.
-template <int MODE, int NL, int T>   // T threads, chunk = 2 T rows; NL = 16-byte loads per thread per slab = ceil(sw / 2T)
+// Cache policy of the sweep kernel's global accesses (NT).  Streams that are touched once per launch (pattern ids,
+// the per-row vectors r / x / rhs / 1/diag, every store) are nontemporal so they do not push the window lines out
+// of L2: neighbouring blocks re-read each other's halo rows there.  Measured at 512^3 (CG iteration / SpMV+dot):
+// all default 1.661 ms / 0.470 ms; nontemporal stores 1.647 / 0.452; + nontemporal single-use loads 1.533 / 0.447;
+// window loads nontemporal as well: 1.856 / 0.539 (the halos miss) -- so the window keeps the default policy.
+// Only when the vectors outgrow the 256 MB Infinity Cache: below ~10 M rows the next kernel finds them there and
+// the default policy wins by 5-7 % (128^3, 192^3, 2048^2), above it nontemporal wins by 9 % (256^3) -- see nt_rows().
+template <bool NT, typename V>
+__device__ __forceinline__ void sweep_st(V *ptr, V v) {
+  if (NT) __builtin_nontemporal_store(v, ptr); else *ptr = v;
+}
+template <bool NT, typename V>
+__device__ __forceinline__ V sweep_ld(const V *ptr) {
+  return NT ? __builtin_nontemporal_load(ptr) : *ptr;
+}
+#define MK_SWEEP_ST(ptr, v) sweep_st<NT>((ptr), (v))
+#define MK_SWEEP_LD(ptr) sweep_ld<NT>(ptr)
+#define MK_SWEEP_LDW(ptr) (*(ptr))
+template <int MODE, int NL, int T, bool NT>   // T threads, chunk = 2 T rows; NL = 16-byte loads per thread per slab = ceil(sw / 2T)
 __global__ __launch_bounds__(T, T == 512 ? 2 : 1) void spmv_sweep_kernel(
     const SweepArgs S, const SweepEntry *__restrict__ etab, int64_t nrows, int64_t ncols, const unsigned short *__restrict__ pat,
     const unsigned *__restrict__ pmask, int npat, const double *__restrict__ x, double *__restrict__ y, double alpha, double beta, double *__restrict__ slab,
@@ -1124,8 +1144,8 @@ __global__ __launch_bounds__(T, T == 512 ? 2 : 1) void spmv_sweep_kernel(
 #pragma unroll
       for (int i = 0; i < NL; i++) {
         const int g = min(max(g0 + i * 2 * T, 0), xlast);
-        reg[i] = *reinterpret_cast<const d2_t *>(reinterpret_cast<const char *>(x) + ((unsigned)g << 3));
-        if (MODE == 5) regr[i] = *reinterpret_cast<const d2_t *>(reinterpret_cast<const char *>(rhs) + ((unsigned)g << 3));
+        reg[i] = MK_SWEEP_LDW(reinterpret_cast<const d2_t *>(reinterpret_cast<const char *>(x) + ((unsigned)g << 3)));
+        if (MODE == 5) regr[i] = MK_SWEEP_LDW(reinterpret_cast<const d2_t *>(reinterpret_cast<const char *>(rhs) + ((unsigned)g << 3)));
       }
     };
     auto write_slab = [&](int slot, int j, const d2_t(&reg)[NL], const d2_t(&regr)[NLR]) {
@@ -1144,7 +1164,7 @@ __global__ __launch_bounds__(T, T == 512 ? 2 : 1) void spmv_sweep_kernel(
             const int own = wi - S.wlo;   // the block's own rows of its own planes go to the new p
             if (j >= k0 && j < k1 && own >= 0 && own < rows_here) {
               const int g = j * S.P + r0 + own;
-              if (g + 1 < nr) *reinterpret_cast<d2_t *>(reinterpret_cast<char *>(y) + ((unsigned)g << 3)) = v;
+              if (g + 1 < nr) MK_SWEEP_ST(reinterpret_cast<d2_t *>(reinterpret_cast<char *>(y) + ((unsigned)g << 3)), v);
               else if (g < nr) *reinterpret_cast<double *>(reinterpret_cast<char *>(y) + ((unsigned)g << 3)) = v.x;
             }
           }
@@ -1156,11 +1176,11 @@ __global__ __launch_bounds__(T, T == 512 ? 2 : 1) void spmv_sweep_kernel(
     auto live = [&](int j) -> bool { return j < k1 && lr < rows_here && row_of(j) < nr; };
     auto load_ids = [&](int j) -> unsigned {   // pattern ids of rows g, g+1 (g even); the id behind the last row is slack
       const int g = min(row_of(j), rlast);
-      return *reinterpret_cast<const unsigned *>(reinterpret_cast<const char *>(pat) + ((unsigned)g << 1));
+      return MK_SWEEP_LD(reinterpret_cast<const unsigned *>(reinterpret_cast<const char *>(pat) + ((unsigned)g << 1)));
     };
     auto load_pair = [&](const double *p, int j) -> d2_t {   // p[g], p[g+1]; p[nrows] is allocation slack
       const int g = min(row_of(j), rlast);
-      return *reinterpret_cast<const d2_t *>(reinterpret_cast<const char *>(p) + ((unsigned)g << 3));
+      return MK_SWEEP_LD(reinterpret_cast<const d2_t *>(reinterpret_cast<const char *>(p) + ((unsigned)g << 3)));
     };
     const double *aux = (MODE == 2 || MODE == 4) ? rhs : (MODE == 0 && beta != 0.0) ? y : nullptr;
     constexpr bool kExtra = (MODE == 2 || MODE == 4);
@@ -1262,7 +1282,7 @@ __global__ __launch_bounds__(T, T == 512 ? 2 : 1) void spmv_sweep_kernel(
               acc2 += xv.x * xv.x;
               if (two) {
                 acc2 += xv.y * xv.y;
-                *reinterpret_cast<d2_t *>(reinterpret_cast<char *>(xupd) + ((unsigned)g << 3)) = xv;
+                MK_SWEEP_ST(reinterpret_cast<d2_t *>(reinterpret_cast<char *>(xupd) + ((unsigned)g << 3)), xv);
               } else {
                 *reinterpret_cast<double *>(reinterpret_cast<char *>(xupd) + ((unsigned)g << 3)) = xv.x;
               }
@@ -1286,7 +1306,7 @@ __global__ __launch_bounds__(T, T == 512 ? 2 : 1) void spmv_sweep_kernel(
           }
         }
         if (MODE != 3 && MODE != 5) {
-          if (two) *reinterpret_cast<d2_t *>(reinterpret_cast<char *>(y) + ((unsigned)g << 3)) = out;
+          if (two) MK_SWEEP_ST(reinterpret_cast<d2_t *>(reinterpret_cast<char *>(y) + ((unsigned)g << 3)), out);
           else *reinterpret_cast<double *>(reinterpret_cast<char *>(y) + ((unsigned)g << 3)) = out.x;
         }
       }
@@ -1363,9 +1383,10 @@ static int launch_sweep(const mk_matrix *A, double alpha, const double *x, doubl
   if (nblocks) *nblocks = blocks;
   const int T = S.C / 2;
   const int nl = std::max(2, (S.sw + 2 * T - 1) / (2 * T));
+  const bool nt = nt_rows(A->nrows);
 #define MK_LAUNCH_SW(NLL, TT)                                                                                              \
   {                                                                                                                        \
-    auto kern = spmv_sweep_kernel<MODE, NLL, TT>;                                                                          \
+    auto kern = nt ? spmv_sweep_kernel<MODE, NLL, TT, true> : spmv_sweep_kernel<MODE, NLL, TT, false>;                     \
     if (lds > 48 * 1024 && !A->sweep_lds_set[MODE]) {                                                                      \
       MK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
       A->sweep_lds_set[MODE] = 1;                                                                                          \
