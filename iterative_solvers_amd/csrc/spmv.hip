@@ -1430,7 +1430,7 @@ __global__ void split_chunk_rows_kernel(int64_t nrows, int64_t nnz, const int *_
   }
 }
 
-template <int MODE>
+template <int MODE, bool NT>   // NT: the matrix does not fit the Infinity Cache, it streams past nontemporally and the caches keep x
 __global__ __launch_bounds__(kThreads) void spmv_split_kernel(
     int64_t nrows, int64_t nnz, const int *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ val,
     const int *__restrict__ chunk_row, int nchunks, const double *__restrict__ x, double *__restrict__ y, double alpha,
@@ -1449,8 +1449,10 @@ __global__ __launch_bounds__(kThreads) void spmv_split_kernel(
       const int64_t k = e0 + (int64_t)(tid + i * kThreads) * 2;
       double p0 = 0.0, p1 = 0.0;
       if (k < e1) {
-        const double2 v = *reinterpret_cast<const double2 *>(val + k);
-        const int2 cc = *reinterpret_cast<const int2 *>(col + k);
+        // the matrix streams past once; x is what the caches are for
+        typedef int i2_t __attribute__((ext_vector_type(2)));
+        const d2_t v = NT ? __builtin_nontemporal_load(reinterpret_cast<const d2_t *>(val + k)) : *reinterpret_cast<const d2_t *>(val + k);
+        const i2_t cc = NT ? __builtin_nontemporal_load(reinterpret_cast<const i2_t *>(col + k)) : *reinterpret_cast<const i2_t *>(col + k);
         p0 = v.x * x[cc.x];
         if (k + 1 < e1) p1 = v.y * x[cc.y];
       }
@@ -1471,8 +1473,8 @@ __global__ __launch_bounds__(kThreads) void spmv_split_kernel(
       double sum = 0.0;
       int64_t sb = 0, se = 0, t_r = 0;
       if (!entering || has_in) {
-        t_r = rowptr[r + 1];
-        sb = entering ? e0 : (int64_t)rowptr[r];
+        t_r = NT ? __builtin_nontemporal_load(rowptr + r + 1) : rowptr[r + 1];
+        sb = entering ? e0 : (int64_t)(NT ? __builtin_nontemporal_load(rowptr + r) : rowptr[r]);
         se = min(t_r, e1);
         for (int64_t j = sb + g; j < se; j += lp) sum += prod[j - e0];
       }
@@ -1482,9 +1484,10 @@ __global__ __launch_bounds__(kThreads) void spmv_split_kernel(
           carry[2 * c] = sum;                                     // folded by the fix-up kernel
         } else if (t_r <= e1) {                                   // starts and ends here: final
           if (MODE == 0) {
-            y[r] = (beta == 0.0) ? alpha * sum : alpha * sum + beta * y[r];
+            const double yv = (beta == 0.0) ? alpha * sum : alpha * sum + beta * y[r];
+            if (NT) __builtin_nontemporal_store(yv, y + r); else y[r] = yv;
           } else {
-            y[r] = sum;
+            if (NT) __builtin_nontemporal_store(sum, y + r); else y[r] = sum;
             const double xr = x[r];
             acc_yx += sum * xr;
             acc_xx += xr * xr;
@@ -1566,8 +1569,14 @@ static int launch_split(const mk_matrix *A, double alpha, const double *x, doubl
   const int main_blocks = std::max(1, std::min(A->nchunks, c.num_cus * 8));
   const int fix_blocks = std::max(1, std::min((A->nchunks + kThreads - 1) / kThreads, 1024));
   if (nblocks) *nblocks = main_blocks + fix_blocks;
-  hipLaunchKernelGGL((spmv_split_kernel<MODE>), dim3(main_blocks), dim3(kThreads), 0, c.stream, A->nrows, A->nnz, A->rowptr, A->col,
-                     A->val, A->chunk_row, A->nchunks, x, y, alpha, beta, A->carry, slab, done);
+  // R-MAT 2^28 entries, x = 134 MB: 3.96 -> 3.54 ms with the matrix stream nontemporal (fewer x gathers miss)
+  if ((double)A->nnz * 12.0 > 200e6) {
+    hipLaunchKernelGGL((spmv_split_kernel<MODE, true>), dim3(main_blocks), dim3(kThreads), 0, c.stream, A->nrows, A->nnz, A->rowptr, A->col,
+                       A->val, A->chunk_row, A->nchunks, x, y, alpha, beta, A->carry, slab, done);
+  } else {
+    hipLaunchKernelGGL((spmv_split_kernel<MODE, false>), dim3(main_blocks), dim3(kThreads), 0, c.stream, A->nrows, A->nnz, A->rowptr, A->col,
+                       A->val, A->chunk_row, A->nchunks, x, y, alpha, beta, A->carry, slab, done);
+  }
   hipLaunchKernelGGL((split_fixup_kernel<MODE>), dim3(fix_blocks), dim3(kThreads), 0, c.stream, A->nrows, A->nnz, A->rowptr,
                      A->chunk_row, A->nchunks, x, y, alpha, beta, A->carry, slab ? slab + main_blocks : nullptr, done);
   MK_HIP(hipGetLastError());

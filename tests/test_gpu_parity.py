@@ -475,6 +475,25 @@ def test_spmv_split_kernel_row_splitting(case):
         assert A.info().long_rows == 1
 
 
+def test_spmv_split_kernel_large_matrix_stream():
+    """above 200 MB of (col, val) the split kernel reads the matrix nontemporally (other instantiation): 20 M entries"""
+    scale, ne = 18, 20_000_000
+    d = mk.DeviceCOO.rmat(scale, ne, seed=9)
+    A = mk.Matrix.from_device_coo(d)
+    assert A.info().kernel == mk.SPMV_SPLIT and A.info().nnz == ne
+    rp, ci, val = A.to_csr()
+    n = 1 << scale
+    _check_spmv(A, rp, ci, val, n, n, np.random.default_rng(2))
+    _check_spmv(A, rp, ci, val, n, n, np.random.default_rng(3), alpha=0.5, beta=-1.5)
+    xh = np.random.default_rng(4).normal(size=n)
+    x, y = mk.Vector(n, values=xh), mk.Vector(n)
+    ytx, xtx = A.spmv_dot(x, y)
+    ref = oracle.csr_spmv(rp, ci, val, xh)
+    mag = oracle.csr_spmv(rp, ci, np.abs(val), np.abs(xh))
+    assert (np.abs(y.get() - ref) / np.maximum(mag, 1e-300)).max() <= SPMV_RTOL
+    assert abs(ytx - ref @ xh) <= 1e-12 * (mag @ np.abs(xh))
+
+
 def test_spmv_split_fused_dot_square():
     scale, ne = 13, 1 << 18
     r, c, v = oracle.rmat_coo(scale, ne, seed=3)
