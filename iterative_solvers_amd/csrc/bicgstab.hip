@@ -32,12 +32,25 @@ constexpr double kEpsMac = 1.e-128;
 // partials of <a1,b1> (component 0) and, when a2 != null, <a2,b2> (component 1)
 static __global__ __launch_bounds__(kVecThreads) void dot2_kernel(int64_t n, const double *__restrict__ a1, const double *__restrict__ b1,
                                                                   const double *__restrict__ a2, const double *__restrict__ b2,
-                                                                  double *__restrict__ slab, const int *__restrict__ done) {
+                                                                  double *__restrict__ slab, const int *__restrict__ done, int nt) {
   if (done != nullptr && *done != 0) return;
   double v[2] = {0.0, 0.0};
-  for (int64_t i = (int64_t)blockIdx.x * kVecThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kVecThreads) {
-    v[0] += a1[i] * b1[i];
-    if (a2) v[1] += a2[i] * b2[i];
+  const int64_t n2 = n >> 1;
+  auto rows = [&](auto tag) {
+    constexpr bool NT = decltype(tag)::value;
+    for (int64_t i = (int64_t)blockIdx.x * kVecThreads + threadIdx.x; i < n2; i += (int64_t)gridDim.x * kVecThreads) {
+      const double2 x1 = vec_ld<NT>(reinterpret_cast<const double2 *>(a1) + i), y1 = vec_ld<NT>(reinterpret_cast<const double2 *>(b1) + i);
+      v[0] += x1.x * y1.x + x1.y * y1.y;
+      if (a2) {
+        const double2 x2 = vec_ld<NT>(reinterpret_cast<const double2 *>(a2) + i), y2 = vec_ld<NT>(reinterpret_cast<const double2 *>(b2) + i);
+        v[1] += x2.x * y2.x + x2.y * y2.y;
+      }
+    }
+  };
+  if (nt) rows(std::true_type{}); else rows(std::false_type{});
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    v[0] += a1[n - 1] * b1[n - 1];
+    if (a2) v[1] += a2[n - 1] * b2[n - 1];
   }
   __shared__ double smem[2 * (kVecThreads / 64)];
   block_sum<2, kVecThreads>(v, smem);
@@ -87,7 +100,7 @@ static __global__ __launch_bounds__(kVecThreads) void bicg_init_scalars_kernel(c
 // alpha = res / <r0,q>;  x += alpha p;  r -= alpha q
 static __global__ __launch_bounds__(kVecThreads) void bicg_step1_kernel(int64_t n, const double *__restrict__ p, const double *__restrict__ q,
                                                                         double *__restrict__ x, double *__restrict__ r,
-                                                                        const double *__restrict__ slab_in, int nblocks_in, BicgState *st) {
+                                                                        const double *__restrict__ slab_in, int nblocks_in, BicgState *st, int nt) {
   if (st->done != 0) return;
   __shared__ double smem[kVecThreads / 64];
   double d[1];
@@ -99,9 +112,22 @@ static __global__ __launch_bounds__(kVecThreads) void bicg_step1_kernel(int64_t 
     return;
   }
   const double alpha = res / temp;
-  for (int64_t i = (int64_t)blockIdx.x * kVecThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kVecThreads) {
-    x[i] += alpha * p[i];
-    r[i] -= alpha * q[i];
+  const int64_t n2 = n >> 1;
+  auto rows = [&](auto tag) {
+    constexpr bool NT = decltype(tag)::value;
+    for (int64_t i = (int64_t)blockIdx.x * kVecThreads + threadIdx.x; i < n2; i += (int64_t)gridDim.x * kVecThreads) {
+      const double2 pv = vec_ld<NT>(reinterpret_cast<const double2 *>(p) + i), qv = vec_ld<NT>(reinterpret_cast<const double2 *>(q) + i);
+      double2 xv = vec_ld<NT>(reinterpret_cast<const double2 *>(x) + i), rv = vec_ld<NT>(reinterpret_cast<const double2 *>(r) + i);
+      xv.x += alpha * pv.x; xv.y += alpha * pv.y;
+      rv.x -= alpha * qv.x; rv.y -= alpha * qv.y;
+      vec_st<NT>(reinterpret_cast<double2 *>(x) + i, xv);
+      vec_st<NT>(reinterpret_cast<double2 *>(r) + i, rv);
+    }
+  };
+  if (nt) rows(std::true_type{}); else rows(std::false_type{});
+  if ((n & 1) && leader) {
+    x[n - 1] += alpha * p[n - 1];
+    r[n - 1] -= alpha * q[n - 1];
   }
   if (leader) { st->alpha = alpha; st->iter += 1; }
 }
@@ -109,18 +135,32 @@ static __global__ __launch_bounds__(kVecThreads) void bicg_step1_kernel(int64_t 
 // gamma = <r,s>/<s,s> (0/0 := 0);  x += gamma r;  r -= gamma s;  partial of <r,r>
 static __global__ __launch_bounds__(kVecThreads) void bicg_step2_kernel(int64_t n, const double *__restrict__ s, double *__restrict__ x,
                                                                         double *__restrict__ r, const double *__restrict__ slab_in,
-                                                                        int nblocks_in, double *__restrict__ slab_out, BicgState *st) {
+                                                                        int nblocks_in, double *__restrict__ slab_out, BicgState *st, int nt) {
   if (st->done != 0) return;
   __shared__ double smem[2 * (kVecThreads / 64)];
   double d[2];
   reduce_slab<2, kVecThreads>(slab_in, nblocks_in, kSlabStride, d, smem);
   const double gamma = (d[0] == 0.0 && d[1] == 0.0) ? 0.0 : d[0] / d[1];
   double v[2] = {0.0, 0.0};
-  for (int64_t i = (int64_t)blockIdx.x * kVecThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kVecThreads) {
-    double ri = r[i];
-    x[i] += gamma * ri;
-    ri -= gamma * s[i];
-    r[i] = ri;
+  const int64_t n2 = n >> 1;
+  auto rows = [&](auto tag) {
+    constexpr bool NT = decltype(tag)::value;
+    for (int64_t i = (int64_t)blockIdx.x * kVecThreads + threadIdx.x; i < n2; i += (int64_t)gridDim.x * kVecThreads) {
+      double2 rv = vec_ld<NT>(reinterpret_cast<const double2 *>(r) + i), xv = vec_ld<NT>(reinterpret_cast<const double2 *>(x) + i);
+      const double2 sv = vec_ld<NT>(reinterpret_cast<const double2 *>(s) + i);
+      xv.x += gamma * rv.x; xv.y += gamma * rv.y;
+      rv.x -= gamma * sv.x; rv.y -= gamma * sv.y;
+      vec_st<NT>(reinterpret_cast<double2 *>(x) + i, xv);
+      vec_st<NT>(reinterpret_cast<double2 *>(r) + i, rv);
+      v[0] += rv.x * rv.x + rv.y * rv.y;
+    }
+  };
+  if (nt) rows(std::true_type{}); else rows(std::false_type{});
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    double ri = r[n - 1];
+    x[n - 1] += gamma * ri;
+    ri -= gamma * s[n - 1];
+    r[n - 1] = ri;
     v[0] += ri * ri;
   }
   block_sum<2, kVecThreads>(v, smem);
@@ -151,7 +191,7 @@ static __global__ void copy_unless_kernel(double *__restrict__ dst, const double
 // Convergence on the true residual; beta = (<r0,r>/res)(alpha/gamma); p = beta (p - gamma q) + r
 static __global__ __launch_bounds__(kVecThreads) void bicg_step3_kernel(int64_t n, const double *__restrict__ r, const double *__restrict__ q,
                                                                         double *__restrict__ p, const double *__restrict__ slab_in,
-                                                                        int nblocks_in, BicgState *st) {
+                                                                        int nblocks_in, BicgState *st, int nt) {
   if (st->done != 0) return;
   __shared__ double smem[2 * (kVecThreads / 64)];
   double d[2];
@@ -181,10 +221,23 @@ static __global__ __launch_bounds__(kVecThreads) void bicg_step3_kernel(int64_t 
     return;
   }
   beta /= gamma;
-  for (int64_t i = (int64_t)blockIdx.x * kVecThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kVecThreads) {
-    double t = p[i] + (-gamma) * q[i];
+  const int64_t n2 = n >> 1;
+  auto rows = [&](auto tag) {
+    constexpr bool NT = decltype(tag)::value;
+    for (int64_t i = (int64_t)blockIdx.x * kVecThreads + threadIdx.x; i < n2; i += (int64_t)gridDim.x * kVecThreads) {
+      double2 pv = vec_ld<NT>(reinterpret_cast<const double2 *>(p) + i);
+      const double2 qv = vec_ld<NT>(reinterpret_cast<const double2 *>(q) + i), rv = vec_ld<NT>(reinterpret_cast<const double2 *>(r) + i);
+      double t0 = pv.x + (-gamma) * qv.x, t1 = pv.y + (-gamma) * qv.y;
+      t0 = beta * t0; t1 = beta * t1;
+      pv.x = t0 + rv.x; pv.y = t1 + rv.y;
+      vec_st<NT>(reinterpret_cast<double2 *>(p) + i, pv);
+    }
+  };
+  if (nt) rows(std::true_type{}); else rows(std::false_type{});
+  if ((n & 1) && leader) {
+    double t = p[n - 1] + (-gamma) * q[n - 1];
     t = beta * t;
-    p[i] = t + r[i];
+    p[n - 1] = t + r[n - 1];
   }
   if (leader) st->res = res;
 }
@@ -274,6 +327,7 @@ int mk_bicgstab_solve(mk_bicgstab *S, const mk_matrix *A, const mk_vector *b, mk
   S->iterations = 0; S->rel_res_norm = 0.0; S->converged = 0; S->breakdown = 0;
   if (n == 0) return MK_OK;
   const int vb = vec_blocks(n);
+  const int nt = (int)nt_rows(n);   // nontemporal vector streams once they outgrow the Infinity Cache
   const dim3 grid(vb), block(kVecThreads);
   BicgState *hst = static_cast<BicgState *>(c.pinned);
 
@@ -286,17 +340,17 @@ int mk_bicgstab_solve(mk_bicgstab *S, const mk_matrix *A, const mk_vector *b, mk
   for (int it = 0; it < S->max_iter && !stop; it++) {
     int *done = &S->state->done, *skip = &S->state->skip_true;
     MK_TRY(launch_spmv(A, 1.0, S->p, 0.0, S->q, done));
-    hipLaunchKernelGGL(dot2_kernel, grid, block, 0, c.stream, n, S->r0, S->q, nullptr, nullptr, S->slab1, done);
-    hipLaunchKernelGGL(bicg_step1_kernel, grid, block, 0, c.stream, n, S->p, S->q, x->d, S->r, S->slab1, vb, S->state);
+    hipLaunchKernelGGL(dot2_kernel, grid, block, 0, c.stream, n, S->r0, S->q, nullptr, nullptr, S->slab1, done, nt);
+    hipLaunchKernelGGL(bicg_step1_kernel, grid, block, 0, c.stream, n, S->p, S->q, x->d, S->r, S->slab1, vb, S->state, nt);
     MK_TRY(launch_spmv(A, 1.0, S->r, 0.0, S->s, done));
-    hipLaunchKernelGGL(dot2_kernel, grid, block, 0, c.stream, n, S->r, S->s, S->s, S->s, S->slab2, done);
-    hipLaunchKernelGGL(bicg_step2_kernel, grid, block, 0, c.stream, n, S->s, x->d, S->r, S->slab2, vb, S->slab1, S->state);
+    hipLaunchKernelGGL(dot2_kernel, grid, block, 0, c.stream, n, S->r, S->s, S->s, S->s, S->slab2, done, nt);
+    hipLaunchKernelGGL(bicg_step2_kernel, grid, block, 0, c.stream, n, S->s, x->d, S->r, S->slab2, vb, S->slab1, S->state, nt);
     hipLaunchKernelGGL(bicg_norm_kernel, dim3(1), block, 0, c.stream, S->slab1, vb, S->state, S->norms);
     // only when the recursive residual passed: r = b - A x (skip_true is 1 otherwise, and after a stop)
     hipLaunchKernelGGL(copy_unless_kernel, grid, dim3(256), 0, c.stream, S->r, b->d, n, skip);
     MK_TRY(launch_spmv(A, -1.0, x->d, 1.0, S->r, skip));
-    hipLaunchKernelGGL(dot2_kernel, grid, block, 0, c.stream, n, S->r0, S->r, S->r, S->r, S->slab2, done);
-    hipLaunchKernelGGL(bicg_step3_kernel, grid, block, 0, c.stream, n, S->r, S->q, S->p, S->slab2, vb, S->state);
+    hipLaunchKernelGGL(dot2_kernel, grid, block, 0, c.stream, n, S->r0, S->r, S->r, S->r, S->slab2, done, nt);
+    hipLaunchKernelGGL(bicg_step3_kernel, grid, block, 0, c.stream, n, S->r, S->q, S->p, S->slab2, vb, S->state, nt);
     if ((it + 1) % S->check_every == 0) {
       MK_HIP(hipMemcpyAsync(&hst[0], S->state, sizeof(BicgState), hipMemcpyDeviceToHost, c.stream));
       MK_HIP(hipStreamSynchronize(c.stream));
@@ -429,18 +483,32 @@ static __global__ __launch_bounds__(kVecThreads) void cgnr_init_scalars_kernel(c
 static __global__ __launch_bounds__(kVecThreads) void cgnr_step1_kernel(int64_t n, const double *__restrict__ p, const double *__restrict__ q,
                                                                         double *__restrict__ x, double *__restrict__ r,
                                                                         const double *__restrict__ slab_in, int nblocks_in,
-                                                                        double *__restrict__ slab_out, CgnrState *st) {
+                                                                        double *__restrict__ slab_out, CgnrState *st, int nt) {
   if (st->done != 0) return;
   __shared__ double smem[kVecThreads / 64];
   double d[1];
   reduce_slab<1, kVecThreads>(slab_in, nblocks_in, kSlabStride, d, smem);
   const double alpha = st->gamma / d[0];
   double v[1] = {0.0};
-  for (int64_t i = (int64_t)blockIdx.x * kVecThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kVecThreads) {
-    x[i] += alpha * p[i];
-    double ri = r[i];
-    ri -= alpha * q[i];
-    r[i] = ri;
+  const int64_t n2 = n >> 1;
+  auto rows = [&](auto tag) {
+    constexpr bool NT = decltype(tag)::value;
+    for (int64_t i = (int64_t)blockIdx.x * kVecThreads + threadIdx.x; i < n2; i += (int64_t)gridDim.x * kVecThreads) {
+      const double2 pv = vec_ld<NT>(reinterpret_cast<const double2 *>(p) + i), qv = vec_ld<NT>(reinterpret_cast<const double2 *>(q) + i);
+      double2 xv = vec_ld<NT>(reinterpret_cast<const double2 *>(x) + i), rv = vec_ld<NT>(reinterpret_cast<const double2 *>(r) + i);
+      xv.x += alpha * pv.x; xv.y += alpha * pv.y;
+      rv.x -= alpha * qv.x; rv.y -= alpha * qv.y;
+      vec_st<NT>(reinterpret_cast<double2 *>(x) + i, xv);
+      vec_st<NT>(reinterpret_cast<double2 *>(r) + i, rv);
+      v[0] += rv.x * rv.x + rv.y * rv.y;
+    }
+  };
+  if (nt) rows(std::true_type{}); else rows(std::false_type{});
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    x[n - 1] += alpha * p[n - 1];
+    double ri = r[n - 1];
+    ri -= alpha * q[n - 1];
+    r[n - 1] = ri;
     v[0] += ri * ri;
   }
   block_sum<1, kVecThreads>(v, smem);
@@ -467,7 +535,7 @@ static __global__ __launch_bounds__(kVecThreads) void cgnr_norm_kernel(const dou
 
 // slab_in: <r,r> of r as it stands now (b - A x if it was a candidate).  beta = gamma/gamma_old; p = beta p + t
 static __global__ __launch_bounds__(kVecThreads) void cgnr_step2_kernel(int64_t n, const double *__restrict__ t, double *__restrict__ p,
-                                                                        const double *__restrict__ slab_in, int nblocks_in, CgnrState *st) {
+                                                                        const double *__restrict__ slab_in, int nblocks_in, CgnrState *st, int nt) {
   if (st->done != 0) return;
   __shared__ double smem[kVecThreads / 64];
   const bool leader = (blockIdx.x == 0 && threadIdx.x == 0);
@@ -483,8 +551,19 @@ static __global__ __launch_bounds__(kVecThreads) void cgnr_step2_kernel(int64_t 
     }
   }
   const double beta = gamma / gamma_old;
-  for (int64_t i = (int64_t)blockIdx.x * kVecThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kVecThreads)
-    p[i] = __dadd_rn(__dmul_rn(beta, p[i]), t[i]);   // hypre scales p, then adds t: two roundings
+  const int64_t n2 = n >> 1;   // hypre scales p, then adds t: two roundings
+  auto rows = [&](auto tag) {
+    constexpr bool NT = decltype(tag)::value;
+    for (int64_t i = (int64_t)blockIdx.x * kVecThreads + threadIdx.x; i < n2; i += (int64_t)gridDim.x * kVecThreads) {
+      double2 pv = vec_ld<NT>(reinterpret_cast<const double2 *>(p) + i);
+      const double2 tv = vec_ld<NT>(reinterpret_cast<const double2 *>(t) + i);
+      pv.x = __dadd_rn(__dmul_rn(beta, pv.x), tv.x);
+      pv.y = __dadd_rn(__dmul_rn(beta, pv.y), tv.y);
+      vec_st<NT>(reinterpret_cast<double2 *>(p) + i, pv);
+    }
+  };
+  if (nt) rows(std::true_type{}); else rows(std::false_type{});
+  if ((n & 1) && leader) p[n - 1] = __dadd_rn(__dmul_rn(beta, p[n - 1]), t[n - 1]);
 }
 
 }  // namespace mk
@@ -573,6 +652,7 @@ int mk_cgnr_solve(mk_cgnr *S, const mk_matrix *A, const mk_vector *b, mk_vector 
   S->iterations = 0; S->rel_res_norm = 0.0; S->converged = 0;
   if (n == 0) return MK_OK;
   const int vb = vec_blocks(n);
+  const int nt = (int)nt_rows(n);
   const dim3 grid(vb), block(kVecThreads);
   CgnrState *hst = static_cast<CgnrState *>(c.pinned);
 
@@ -595,16 +675,16 @@ int mk_cgnr_solve(mk_cgnr *S, const mk_matrix *A, const mk_vector *b, mk_vector 
   for (int it = 0; it < S->max_iter && !stop; it++) {
     int *done = &S->state->done, *skip = &S->state->skip_true;
     MK_TRY(launch_spmv(A, 1.0, S->p, 0.0, S->q, done));
-    hipLaunchKernelGGL(dot2_kernel, grid, block, 0, c.stream, n, S->q, S->q, nullptr, nullptr, S->slab1, done);
-    hipLaunchKernelGGL(cgnr_step1_kernel, grid, block, 0, c.stream, n, S->p, S->q, x->d, S->r, S->slab1, vb, S->slab2, S->state);
+    hipLaunchKernelGGL(dot2_kernel, grid, block, 0, c.stream, n, S->q, S->q, nullptr, nullptr, S->slab1, done, nt);
+    hipLaunchKernelGGL(cgnr_step1_kernel, grid, block, 0, c.stream, n, S->p, S->q, x->d, S->r, S->slab1, vb, S->slab2, S->state, nt);
     MK_TRY(launch_spmv(S->AT, 1.0, S->r, 0.0, S->t, done));
-    hipLaunchKernelGGL(dot2_kernel, grid, block, 0, c.stream, n, S->t, S->t, nullptr, nullptr, S->slab3, done);
+    hipLaunchKernelGGL(dot2_kernel, grid, block, 0, c.stream, n, S->t, S->t, nullptr, nullptr, S->slab3, done, nt);
     hipLaunchKernelGGL(cgnr_norm_kernel, dim3(1), block, 0, c.stream, S->slab2, S->slab3, vb, S->state, S->norms);
     // only when <r,r> passed: r = b - A x, and its norm
     hipLaunchKernelGGL(copy_unless_kernel, grid, dim3(256), 0, c.stream, S->r, b->d, n, skip);
     MK_TRY(launch_spmv(A, -1.0, x->d, 1.0, S->r, skip));
-    hipLaunchKernelGGL(dot2_kernel, grid, block, 0, c.stream, n, S->r, S->r, nullptr, nullptr, S->slab1, skip);
-    hipLaunchKernelGGL(cgnr_step2_kernel, grid, block, 0, c.stream, n, S->t, S->p, S->slab1, vb, S->state);
+    hipLaunchKernelGGL(dot2_kernel, grid, block, 0, c.stream, n, S->r, S->r, nullptr, nullptr, S->slab1, skip, nt);
+    hipLaunchKernelGGL(cgnr_step2_kernel, grid, block, 0, c.stream, n, S->t, S->p, S->slab1, vb, S->state, nt);
     if ((it + 1) % S->check_every == 0) {
       MK_HIP(hipMemcpyAsync(&hst[0], S->state, sizeof(CgnrState), hipMemcpyDeviceToHost, c.stream));
       MK_HIP(hipStreamSynchronize(c.stream));
