@@ -55,7 +55,7 @@ static __global__ __launch_bounds__(kVecThreads) void gmres_norm2_kernel(const d
 static __global__ __launch_bounds__(kVecThreads) void gmres_mgs_kernel(int64_t n, double *__restrict__ pi, const double *__restrict__ pprev,
                                                                        const double *__restrict__ pj, const double *__restrict__ slab_in,
                                                                        int nblocks_in, double *__restrict__ slab_out,
-                                                                       double *__restrict__ hcol, int jprev) {
+                                                                       double *__restrict__ hcol, int jprev, int nt) {
   __shared__ double smem[kVecThreads / 64];
   double h = 0.0;
   if (pprev) {
@@ -66,10 +66,31 @@ static __global__ __launch_bounds__(kVecThreads) void gmres_mgs_kernel(int64_t n
   }
   const double mh = -h;
   double v[1] = {0.0};
-  for (int64_t k = (int64_t)blockIdx.x * kVecThreads + threadIdx.x; k < n; k += (int64_t)gridDim.x * kVecThreads) {
+  const int64_t n2 = n >> 1;
+  auto rows = [&](auto tag) {
+    constexpr bool NT = decltype(tag)::value;
+    for (int64_t k = (int64_t)blockIdx.x * kVecThreads + threadIdx.x; k < n2; k += (int64_t)gridDim.x * kVecThreads) {
+      double2 w = vec_ld<NT>(reinterpret_cast<const double2 *>(pi) + k);
+      if (pprev) {
+        const double2 pp = vec_ld<NT>(reinterpret_cast<const double2 *>(pprev) + k);
+        w.x += mh * pp.x;   // hypre: axpy(-h, p[j], p[i])
+        w.y += mh * pp.y;
+        vec_st<NT>(reinterpret_cast<double2 *>(pi) + k, w);
+      }
+      if (pj) {
+        const double2 pjv = vec_ld<NT>(reinterpret_cast<const double2 *>(pj) + k);
+        v[0] += pjv.x * w.x + pjv.y * w.y;
+      } else {
+        v[0] += w.x * w.x + w.y * w.y;
+      }
+    }
+  };
+  if (nt) rows(std::true_type{}); else rows(std::false_type{});
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const int64_t k = n - 1;
     double w = pi[k];
     if (pprev) {
-      w += mh * pprev[k];   // hypre: axpy(-h, p[j], p[i])
+      w += mh * pprev[k];
       pi[k] = w;
     }
     v[0] += (pj ? pj[k] : w) * w;
@@ -193,6 +214,7 @@ int mk_gmres_solve(mk_gmres *S, const mk_matrix *A, const mk_vector *b, mk_vecto
   S->norms.clear();
   if (n == 0) return MK_OK;
   const int vb = vec_blocks(n);
+  const int nt = (int)nt_rows(n);   // the basis vectors stream past nontemporally once they outgrow the Infinity Cache
   const dim3 grid(vb), block(kVecThreads);
   double *hpin = static_cast<double *>(c.pinned);   // k_dim + 2 doubles
   auto P = [&](int j) { return S->basis + (int64_t)j * ld; };
@@ -236,7 +258,7 @@ int mk_gmres_solve(mk_gmres *S, const mk_matrix *A, const mk_vector *b, mk_vecto
       for (int j = 0; j <= i; j++) {
         std::swap(sl_in, sl_out);
         hipLaunchKernelGGL(gmres_mgs_kernel, grid, block, 0, c.stream, n, P(i), j > 0 ? P(j - 1) : (const double *)nullptr,
-                           j < i ? P(j) : (const double *)nullptr, sl_in, vb, sl_out, S->hcol, j - 1);
+                           j < i ? P(j) : (const double *)nullptr, sl_in, vb, sl_out, S->hcol, j - 1, nt);
       }
       hipLaunchKernelGGL(gmres_hnorm_kernel, dim3(1), block, 0, c.stream, sl_out, vb, S->hcol, i);
       MK_HIP(hipMemcpyAsync(hpin, S->hcol, (size_t)(i + 1) * sizeof(double), hipMemcpyDeviceToHost, c.stream));
