@@ -10,7 +10,7 @@
 // recomputes r = b - A x and tests again).  All scalars (alpha, gamma, beta, norms, flags) live
 // in a device record; every reduction is finished in the next kernel's prologue from a slab of
 // per-block partials (fixed order, no atomics); the host polls the stop flag every check_every
-// iterations.  Algorithmic bytes per iteration: 2 SpMV + 168 n.
+// iterations.  Algorithmic bytes per iteration: 2 SpMV + 160 n (the dots step 3 needs ride in step 2).
 #include <cfloat>
 #include <cmath>
 
@@ -132,8 +132,9 @@ static __global__ __launch_bounds__(kVecThreads) void bicg_step1_kernel(int64_t 
   if (leader) { st->alpha = alpha; st->iter += 1; }
 }
 
-// gamma = <r,s>/<s,s> (0/0 := 0);  x += gamma r;  r -= gamma s;  partial of <r,r>
-static __global__ __launch_bounds__(kVecThreads) void bicg_step2_kernel(int64_t n, const double *__restrict__ s, double *__restrict__ x,
+// gamma = <r,s>/<s,s> (0/0 := 0);  x += gamma r;  r -= gamma s;  partials of <r0,r>, <r,r> (what step 3 needs, unless
+// the true residual replaces r in between: then the dot kernel behind it overwrites them)
+static __global__ __launch_bounds__(kVecThreads) void bicg_step2_kernel(int64_t n, const double *__restrict__ s, const double *__restrict__ r0, double *__restrict__ x,
                                                                         double *__restrict__ r, const double *__restrict__ slab_in,
                                                                         int nblocks_in, double *__restrict__ slab_out, BicgState *st, int nt) {
   if (st->done != 0) return;
@@ -152,7 +153,9 @@ static __global__ __launch_bounds__(kVecThreads) void bicg_step2_kernel(int64_t 
       rv.x -= gamma * sv.x; rv.y -= gamma * sv.y;
       vec_st<NT>(reinterpret_cast<double2 *>(x) + i, xv);
       vec_st<NT>(reinterpret_cast<double2 *>(r) + i, rv);
-      v[0] += rv.x * rv.x + rv.y * rv.y;
+      const double2 zv = vec_ld<NT>(reinterpret_cast<const double2 *>(r0) + i);
+      v[0] += zv.x * rv.x + zv.y * rv.y;
+      v[1] += rv.x * rv.x + rv.y * rv.y;
     }
   };
   if (nt) rows(std::true_type{}); else rows(std::false_type{});
@@ -161,10 +164,14 @@ static __global__ __launch_bounds__(kVecThreads) void bicg_step2_kernel(int64_t 
     x[n - 1] += gamma * ri;
     ri -= gamma * s[n - 1];
     r[n - 1] = ri;
-    v[0] += ri * ri;
+    v[0] += r0[n - 1] * ri;
+    v[1] += ri * ri;
   }
   block_sum<2, kVecThreads>(v, smem);
-  if (threadIdx.x == 0) slab_out[blockIdx.x] = v[0];
+  if (threadIdx.x == 0) {
+    slab_out[blockIdx.x] = v[0];
+    slab_out[kSlabStride + blockIdx.x] = v[1];
+  }
   if (blockIdx.x == 0 && threadIdx.x == 0) st->gamma = gamma;
 }
 
@@ -250,7 +257,7 @@ struct mk_bicgstab {
   int print_level = 0, logging = 0, check_every = 16;
   int64_t n = 0;
   double *r0 = nullptr, *r = nullptr, *p = nullptr, *q = nullptr, *s = nullptr;
-  double *slab1 = nullptr, *slab2 = nullptr;
+  double *slab1 = nullptr, *slab2 = nullptr, *slab3 = nullptr;
   mk::BicgState *state = nullptr;
   double *norms = nullptr;
   int norms_cap = 0;
@@ -263,8 +270,8 @@ using namespace mk;
 
 static void bicg_release(mk_bicgstab *S) {
   dev_free(S->r0); dev_free(S->r); dev_free(S->p); dev_free(S->q); dev_free(S->s);
-  dev_free(S->slab1); dev_free(S->slab2); dev_free(S->state); dev_free(S->norms);
-  S->r0 = S->r = S->p = S->q = S->s = S->slab1 = S->slab2 = S->norms = nullptr;
+  dev_free(S->slab1); dev_free(S->slab2); dev_free(S->slab3); dev_free(S->state); dev_free(S->norms);
+  S->r0 = S->r = S->p = S->q = S->s = S->slab1 = S->slab2 = S->slab3 = S->norms = nullptr;
   S->state = nullptr;
   S->n = 0;
 }
@@ -306,6 +313,7 @@ int mk_bicgstab_setup(mk_bicgstab *S, const mk_matrix *A, const mk_vector *b, co
   MK_TRY(dev_alloc(&S->s, (size_t)S->n));
   MK_TRY(dev_alloc(&S->slab1, (size_t)2 * kSlabStride));
   MK_TRY(dev_alloc(&S->slab2, (size_t)2 * kSlabStride));
+  MK_TRY(dev_alloc(&S->slab3, (size_t)2 * kSlabStride));
   MK_TRY(dev_alloc(&S->state, 1));
   if (S->logging > 0 || S->print_level > 0) {
     S->norms_cap = S->max_iter + 1;
@@ -344,13 +352,13 @@ int mk_bicgstab_solve(mk_bicgstab *S, const mk_matrix *A, const mk_vector *b, mk
     hipLaunchKernelGGL(bicg_step1_kernel, grid, block, 0, c.stream, n, S->p, S->q, x->d, S->r, S->slab1, vb, S->state, nt);
     MK_TRY(launch_spmv(A, 1.0, S->r, 0.0, S->s, done));
     hipLaunchKernelGGL(dot2_kernel, grid, block, 0, c.stream, n, S->r, S->s, S->s, S->s, S->slab2, done, nt);
-    hipLaunchKernelGGL(bicg_step2_kernel, grid, block, 0, c.stream, n, S->s, x->d, S->r, S->slab2, vb, S->slab1, S->state, nt);
-    hipLaunchKernelGGL(bicg_norm_kernel, dim3(1), block, 0, c.stream, S->slab1, vb, S->state, S->norms);
+    hipLaunchKernelGGL(bicg_step2_kernel, grid, block, 0, c.stream, n, S->s, S->r0, x->d, S->r, S->slab2, vb, S->slab3, S->state, nt);
+    hipLaunchKernelGGL(bicg_norm_kernel, dim3(1), block, 0, c.stream, S->slab3 + kSlabStride, vb, S->state, S->norms);
     // only when the recursive residual passed: r = b - A x (skip_true is 1 otherwise, and after a stop)
     hipLaunchKernelGGL(copy_unless_kernel, grid, dim3(256), 0, c.stream, S->r, b->d, n, skip);
     MK_TRY(launch_spmv(A, -1.0, x->d, 1.0, S->r, skip));
-    hipLaunchKernelGGL(dot2_kernel, grid, block, 0, c.stream, n, S->r0, S->r, S->r, S->r, S->slab2, done, nt);
-    hipLaunchKernelGGL(bicg_step3_kernel, grid, block, 0, c.stream, n, S->r, S->q, S->p, S->slab2, vb, S->state, nt);
+    hipLaunchKernelGGL(dot2_kernel, grid, block, 0, c.stream, n, S->r0, S->r, S->r, S->r, S->slab3, skip, nt);   // only behind a true residual
+    hipLaunchKernelGGL(bicg_step3_kernel, grid, block, 0, c.stream, n, S->r, S->q, S->p, S->slab3, vb, S->state, nt);
     if ((it + 1) % S->check_every == 0) {
       MK_HIP(hipMemcpyAsync(&hst[0], S->state, sizeof(BicgState), hipMemcpyDeviceToHost, c.stream));
       MK_HIP(hipStreamSynchronize(c.stream));

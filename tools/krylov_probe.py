@@ -30,8 +30,8 @@ for it in (6, iters):
     dt = time.perf_counter() - t0
 i = A.info()
 spmv_b = 18 * n if i.kernel in (4, 5) else 12 * A.nnz + 20 * n
-# vector bytes per iteration: BiCGSTAB 168 n; CGNR 112 n; GMRES(30) cycle average of (32 i + 40) n, i = 1..30
-vec_b = {"bicgstab": 168, "cgnr": 112, "gmres": 32 * 15.5 + 40}[which] * n
+# vector bytes per iteration: BiCGSTAB 160 n; CGNR 112 n; GMRES(30) cycle average of (32 i + 40) n, i = 1..30
+vec_b = {"bicgstab": 160, "cgnr": 112, "gmres": 32 * 15.5 + 40}[which] * n
 nspmv = 1 if which == "gmres" else 2
 print(f"{which} kind={kind} {nx}x{ny}x{nz} kernel={i.kernel}: {r['iterations']} iterations, {dt / r['iterations'] * 1e3:.3f} ms/iteration, "
       f"{r['iterations'] / dt:.1f} it/s, {(nspmv * spmv_b + vec_b) * r['iterations'] / dt / 1e9:.0f} GB/s on the byte model", flush=True)
