@@ -169,6 +169,15 @@ def main():
                      "csr_model_frac": round(csr_bytes / (spmv_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
         "final_rel_res_norm": res["rel_res_norm"],
     }
+    # the timed region itself: one CG iteration = its kernels back to back (two sweeps on the fused path), priced on
+    # the bytes they move; `traffic` is the PMC sum over the kernels of one iteration (profiles/traffic.json)
+    it_traffic = None
+    if os.path.exists(tpath):
+        it_traffic = json.load(open(tpath)).get(name + ":" + kname + ":iteration")
+    it_gbps = iter_bytes / (ms_per_step * 1e-3) / 1e9
+    out["roofline_iteration"] = {"bound": "hbm", "kernel": "whole CG iteration (timed region of `value`)", "achieved": round(it_gbps, 1),
+                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(it_gbps / HBM_PEAK_GBS, 4),
+                                 "bytes_per_iteration": iter_bytes, "traffic": it_traffic}
     del A, b, s
     if args.workload is None:
         # BASELINE.json configs[1] beside the headline: 256^3, Jacobi-preconditioned CG, one GPU
