@@ -32,6 +32,8 @@ WORKLOADS = {
     "lap7_512_cg": (7, 512, 512, 512, 0, "3D 7-pt Laplacian 512^3, CG, fp64 (north-star scaling target)"),
     "poisson5_1024_cg": (5, 1024, 1024, 1, 0, "2D 5-pt Poisson 1024^2, CG, fp64"),
     "lap27_256_cg": (27, 256, 256, 256, 0, "3D 27-pt stencil 256^3, CG, fp64"),
+    # BASELINE configs[3]; 3.6 G entries: row blocks only (--gpus >= 2), one matrix's int32 row pointers cannot hold it
+    "lap27_512_cg": (27, 512, 512, 512, 0, "3D 27-pt stencil 512^3, CG, fp64, row-block partitioned"),
 }
 
 

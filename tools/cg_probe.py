@@ -10,7 +10,7 @@ mk.init(0)
 iters = int(os.environ.get("MK_PROBE_ITERS", "60"))
 for arg in sys.argv[1:]:
     nx, ny, nz = (int(a) for a in arg.split(","))
-    A = mk.Matrix.stencil(7, nx, ny, nz)
+    A = mk.Matrix.stencil(int(os.environ.get("MK_PROBE_KIND", "7")), nx, ny, nz)
     if os.environ.get("MK_PROBE_KERNEL"):
         A.set_spmv_kernel(int(os.environ["MK_PROBE_KERNEL"]))
     n = A.nrows

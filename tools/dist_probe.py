@@ -11,6 +11,7 @@ from iterative_solvers_amd import distributed as mkd
 
 nx, ny, nz, world = (int(a) for a in sys.argv[1:5])
 iters = int(sys.argv[5]) if len(sys.argv) > 5 else 100
+KIND = int(os.environ.get("MK_PROBE_KIND", "7"))
 mk.init(0)
 n = nx * ny * nz
 
@@ -24,7 +25,11 @@ def timed(fn):
     return (time.perf_counter() - t0) / iters * 1e3
 
 
-A = mk.Matrix.stencil(7, nx, ny, nz)
+try:
+    A = mk.Matrix.stencil(KIND, nx, ny, nz)
+except mk.MkError as e:   # e.g. 27-point 512^3: 3.6 G entries do not fit one matrix's int32 row pointers
+    print("single matrix skipped:", e, flush=True)
+    A = None
 b, x = mk.Vector(n, fill=1.0), mk.Vector(n, fill=0.0)
 
 
@@ -35,11 +40,11 @@ def single(it):
     S.solve(A, b, x)
 
 
-ms1 = timed(single)
+ms1 = timed(single) if A is not None else float('nan')
 del A, b, x
 rs = mkd.slab_row_start(nx, ny, nz, world)
 comms = mkd.Comm.local_world(world)
-As = [mkd.DistMatrix(mk.Matrix.stencil(7, nx, ny, nz, row_begin=int(rs[r]), row_end=int(rs[r + 1])), n, rs, comms[r]) for r in range(world)]
+As = [mkd.DistMatrix(mk.Matrix.stencil(KIND, nx, ny, nz, row_begin=int(rs[r]), row_end=int(rs[r + 1])), n, rs, comms[r]) for r in range(world)]
 bs = [a.vector(fill=1.0) for a in As]
 xs = [a.vector(fill=0.0) for a in As]
 
