@@ -377,6 +377,60 @@ def test_spmv_pattern_kernel_wide_addressing():
     assert o.returncode == 0 and "wide ok" in o.stdout, o.stderr[-2000:]
 
 
+@pytest.mark.parametrize("no_value_compression", ["0", "1"])
+def test_nontemporal_instantiations_match_oracle(no_value_compression):
+    """above 10 M rows the single-use streams are nontemporal: other instantiations of the sweep, stream and vector
+    kernels (the ones bench.py runs).  MK_NT=1 forces them on small operators; the switch is read once per
+    process, hence the child.  With value compression off the same solves go through the stream kernel + K2/K3."""
+    import subprocess, sys
+    code = (
+        "import numpy as np, iterative_solvers_amd as mk, oracle\n"
+        "for kind, dims in ((7, (64, 64, 40)), (27, (40, 40, 6)), (7, (640, 4, 6))):\n"
+        "    rp, ci, v = oracle.stencil_csr(kind, *dims)\n"
+        "    n = rp.size - 1\n"
+        "    A = mk.Matrix.from_csr(n, n, rp, ci, v)\n"
+        "    if A.info().value_patterns: A.set_spmv_kernel(mk.SPMV_SWEEP)\n"
+        "    xh = np.random.default_rng(1).normal(size=n)\n"
+        "    x, y = mk.Vector(n, values=xh), mk.Vector(n)\n"
+        "    A.spmv(x, y)\n"
+        "    ref = oracle.csr_spmv(rp, ci, v, xh)\n"
+        "    mag = oracle.csr_spmv(rp, ci, np.abs(v), np.abs(xh))\n"
+        "    same = (lambda got: np.array_equal(got, ref)) if A.info().value_patterns else (lambda got: (np.abs(got - ref) / mag).max() <= 1e-12)\n"
+        "    assert same(y.get())\n"
+        "    yx, xx = A.spmv_dot(x, y)\n"
+        "    assert same(y.get()) and abs(yx - ref @ xh) <= 1e-12 * np.abs(ref * xh).sum()\n"
+        "    for precond in (0, 1):\n"
+        "        o = oracle.pcg(rp, ci, v, np.ones(n), tol=1e-9, precond=precond, maxit=1000, want_norms=True, rel_change=1)\n"
+        "        b, x0 = mk.Vector(n, fill=1.0), mk.Vector(n, fill=0.0)\n"
+        "        S = mk.PCG(max_iter=1000, tol=1e-9, two_norm=1, rel_change=1, precond=precond, logging=1, check_every=5)\n"
+        "        S.setup(A, b, x0)\n"
+        "        r = S.solve(A, b, x0)\n"
+        "        assert r['converged'] == 1 and abs(r['iterations'] - o['iterations']) <= 2, (r, o['iterations'])\n"
+        "        assert np.linalg.norm(x0.get() - o['x']) <= 1e-6 * np.linalg.norm(o['x'])\n"
+        "        h = S.residual_history(2000)\n"
+        "        m = min(h.size, o['rel_norms'].size, 40)\n"
+        "        assert np.allclose(h[:m], o['rel_norms'][:m], rtol=1e-8)\n"
+        "    J = mk.Jacobi(max_iter=30, tol=1e-30, check_every=7)\n"
+        "    xj = mk.Vector(n, fill=0.0)\n"
+        "    b = mk.Vector(n, fill=1.0)\n"
+        "    J.setup(A, b, xj)\n"
+        "    J.solve(A, b, xj)\n"
+        "    oj = oracle.jacobi(rp, ci, v, np.ones(n), maxit=30, tol=1e-30)\n"
+        "    assert np.allclose(xj.get(), oj['x'], rtol=1e-12, atol=1e-14)\n"
+        "    for cls, fn in ((mk.BiCGSTAB, oracle.bicgstab), (mk.CGNR, oracle.cgnr)):\n"
+        "        b, x0 = mk.Vector(n, fill=1.0), mk.Vector(n, fill=0.0)\n"
+        "        S = cls(max_iter=4, tol=1e-30)\n"
+        "        S.setup(A, b, x0)\n"
+        "        S.solve(A, b, x0)\n"
+        "        o = fn(rp, ci, v, np.ones(n), tol=1e-30, maxit=4)\n"
+        "        assert np.linalg.norm(x0.get() - o['x']) <= 1e-9 * np.linalg.norm(o['x'])\n"
+        "print('nt ok')\n")
+    env = dict(os.environ, MK_NT="1", MK_NO_VALUE_COMPRESSION=no_value_compression,
+               PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    o = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=110)
+    assert o.returncode == 0 and "nt ok" in o.stdout, (o.stdout[-500:], o.stderr[-2000:])
+
+
 def test_spmv_index_compression_is_lossless_and_optional():
     """random short rows have ~n distinct patterns: the table would not fit, so the plain stream
     kernel runs; a block-structured matrix with a few hundred patterns is compressed; both must
