@@ -246,10 +246,13 @@ __device__ __forceinline__ void block_sum(double (&v)[NP], double *smem /* NP*(T
 // Vectors of this many rows no longer stay in the 256 MB Infinity Cache between the kernels of an iteration
 // (4 vectors x 8 B x 10 M rows = 320 MB): single-use streams then go nontemporal.  Measured crossover on the sweep
 // path and on the K2/K3 vector kernels alike: 8.4 M rows default policy 2 % ahead, 16.7 M rows nontemporal 5-9 % ahead.
-static inline bool nt_rows(int64_t n) {
-  static const int force = getenv("MK_NT") ? atoi(getenv("MK_NT")) : -1;   // 0 / 1: never / always (A/B)
-  return force >= 0 ? force != 0 : n > 10 * 1000 * 1000;
+static inline int nt_force() {
+  static const int force = getenv("MK_NT") ? atoi(getenv("MK_NT")) : -1;   // 0 / 1: never / always (A/B, tests)
+  return force;
 }
+static inline bool nt_rows(int64_t n) { return nt_force() >= 0 ? nt_force() != 0 : n > 10 * 1000 * 1000; }
+// the matrix streams (val + col) of the stream and split kernels: nontemporal once they exceed the cache
+static inline bool nt_matrix(double bytes) { return nt_force() >= 0 ? nt_force() != 0 : bytes > 200e6; }
 
 // Sum the per-block partials a previous kernel left in a slab (launch-boundary reduce:
 // no in-launch hand-off, so no fences).  Every block computes the same bits.

@@ -762,7 +762,7 @@ static int launch_stream(const mk_matrix *A, double alpha, const double *x, doub
                          const int *done, int *nblocks, const double *rhs = nullptr, const double *extra = nullptr) {
   const int cap = A->stream_cap;
   // values larger than the Infinity Cache are streamed non-temporally
-  const bool nt = (double)A->nnz * 8.0 > 200e6;
+  const bool nt = nt_matrix((double)A->nnz * 8.0);
 #define MK_STREAM_PICK(UU)                                                                                         \
   if (cap <= 1024 * UU - 8) {                                                                                      \
     if (A->pat) return nt ? launch_stream_u<MODE, UU, true, true>(A, alpha, x, beta, y, slab, done, nblocks, rhs, extra)   \
@@ -1570,7 +1570,7 @@ static int launch_split(const mk_matrix *A, double alpha, const double *x, doubl
   const int fix_blocks = std::max(1, std::min((A->nchunks + kThreads - 1) / kThreads, 1024));
   if (nblocks) *nblocks = main_blocks + fix_blocks;
   // R-MAT 2^28 entries, x = 134 MB: 3.96 -> 3.54 ms with the matrix stream nontemporal (fewer x gathers miss)
-  if ((double)A->nnz * 12.0 > 200e6) {
+  if (nt_matrix((double)A->nnz * 12.0)) {
     hipLaunchKernelGGL((spmv_split_kernel<MODE, true>), dim3(main_blocks), dim3(kThreads), 0, c.stream, A->nrows, A->nnz, A->rowptr, A->col,
                        A->val, A->chunk_row, A->nchunks, x, y, alpha, beta, A->carry, slab, done);
   } else {

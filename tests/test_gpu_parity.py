@@ -424,6 +424,17 @@ def test_nontemporal_instantiations_match_oracle(no_value_compression):
         "        S.solve(A, b, x0)\n"
         "        o = fn(rp, ci, v, np.ones(n), tol=1e-30, maxit=4)\n"
         "        assert np.linalg.norm(x0.get() - o['x']) <= 1e-9 * np.linalg.norm(o['x'])\n"
+        "r, c, v = oracle.rmat_coo(13, 1 << 18, seed=3)\n"
+        "n = 1 << 13\n"
+        "rp, ci, val = oracle.coo_to_csr(n, r, c, v)\n"
+        "A = mk.Matrix.from_csr(n, n, rp, ci, val)\n"
+        "assert A.info().kernel == mk.SPMV_SPLIT\n"
+        "xh = np.random.default_rng(1).normal(size=n)\n"
+        "x, y = mk.Vector(n, values=xh), mk.Vector(n)\n"
+        "A.spmv(x, y)\n"
+        "ref = oracle.csr_spmv(rp, ci, val, xh)\n"
+        "mag = oracle.csr_spmv(rp, ci, np.abs(val), np.abs(xh))\n"
+        "assert (np.abs(y.get() - ref) / np.maximum(mag, 1e-300)).max() <= 1e-12\n"
         "print('nt ok')\n")
     env = dict(os.environ, MK_NT="1", MK_NO_VALUE_COMPRESSION=no_value_compression,
                PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
