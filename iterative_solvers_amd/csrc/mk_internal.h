@@ -146,6 +146,11 @@ struct mk_matrix {
   int npat = 0, pml = 0;
   int max_off = 0;                 // largest |column - row| over all patterns
   // split kernel: chunk c covers entries [c*kSplitChunk, (c+1)*kSplitChunk); chunk_row[c] = first row starting in it
+  // split kernel on matrices whose x outgrows the caches: columns renumbered hot-first (convert.hip build_column_relabel)
+  int *col2 = nullptr;       // perm[col[e]]
+  int *xorder = nullptr;     // new position -> old column
+  double *xg = nullptr;      // x in the new order, rebuilt by every product
+  int relabel_tried = 0;
   int *chunk_row = nullptr;
   int nchunks = 0;
   double *carry = nullptr;   // 2 per chunk: partial of the row entering from the left, partial of the row leaving to the right
@@ -199,6 +204,7 @@ int exclusive_scan_u32(const uint32_t *in, uint32_t *out, size_t n, uint32_t *to
 // (they are freed or become the CSR arrays).  sorted_rows_out (optional) receives the
 // sorted row keys (device buffer of nnz ints owned by caller afterwards).
 int device_coo_to_csr(mk_coo *coo, mk_matrix *A, int **sorted_rows_out);
+int build_column_relabel(mk_matrix *A);
 int build_transpose(const mk_matrix *A, mk_matrix **out);   // A^T through the same conversion (cgnr.hip)
 
 }  // namespace mk

@@ -1434,7 +1434,8 @@ template <int MODE, bool NT>   // NT: the matrix does not fit the Infinity Cache
 __global__ __launch_bounds__(kThreads) void spmv_split_kernel(
     int64_t nrows, int64_t nnz, const int *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ val,
     const int *__restrict__ chunk_row, int nchunks, const double *__restrict__ x, double *__restrict__ y, double alpha,
-    double beta, double *__restrict__ carry, double *__restrict__ slab, const int *__restrict__ done) {
+    double beta, double *__restrict__ carry, double *__restrict__ slab, const int *__restrict__ done,
+    const double *__restrict__ xg) {   // xg: the vector the column indices refer to (x, or x in the relabelled order)
   if (done != nullptr && *done != 0) return;
   __shared__ __attribute__((aligned(16))) double prod[kSplitChunk];
   __shared__ double red[2 * (kThreads / 64)];
@@ -1453,8 +1454,8 @@ __global__ __launch_bounds__(kThreads) void spmv_split_kernel(
         typedef int i2_t __attribute__((ext_vector_type(2)));
         const d2_t v = NT ? __builtin_nontemporal_load(reinterpret_cast<const d2_t *>(val + k)) : *reinterpret_cast<const d2_t *>(val + k);
         const i2_t cc = NT ? __builtin_nontemporal_load(reinterpret_cast<const i2_t *>(col + k)) : *reinterpret_cast<const i2_t *>(col + k);
-        p0 = v.x * x[cc.x];
-        if (k + 1 < e1) p1 = v.y * x[cc.y];
+        p0 = v.x * xg[cc.x];
+        if (k + 1 < e1) p1 = v.y * xg[cc.y];
       }
       *reinterpret_cast<double2 *>(prod + (k - e0)) = make_double2(p0, p1);
     }
@@ -1548,7 +1549,22 @@ __global__ __launch_bounds__(kThreads) void split_fixup_kernel(
   }
 }
 
+static __global__ void gather_x_kernel(int64_t n, const int *__restrict__ order, const double *__restrict__ x, double *__restrict__ xg,
+                                       const int *__restrict__ done) {
+  if (done != nullptr && *done != 0) return;
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) xg[j] = x[order[j]];
+}
+
 static int prepare_split(mk_matrix *A) {
+  // x well beyond the 32 MB of L2 and enough entries to pay for one more pass over x per product.  Measured on R-MAT
+  // with 16 entries per row: 2^22 columns 586 us plain / 618 us relabelled, 2^23 1392 / 1161, 2^24 3586 / 2387.
+  static const int no_relabel = getenv("MK_NO_COLUMN_RELABEL") ? atoi(getenv("MK_NO_COLUMN_RELABEL")) : 0;
+  static const int64_t min_cols = getenv("MK_RELABEL_MIN_COLS") ? atoll(getenv("MK_RELABEL_MIN_COLS")) : (int64_t)6 << 20;
+  if (!A->relabel_tried && !no_relabel && A->ncols >= min_cols && A->nnz >= 4 * A->ncols) {
+    A->relabel_tried = 1;
+    MK_TRY(build_column_relabel(A));
+  }
+  A->relabel_tried = 1;
   if (A->chunk_row) return MK_OK;
   Context &c = ctx();
   A->nchunks = (int)((A->nnz + kSplitChunk - 1) / kSplitChunk);
@@ -1570,12 +1586,20 @@ static int launch_split(const mk_matrix *A, double alpha, const double *x, doubl
   const int fix_blocks = std::max(1, std::min((A->nchunks + kThreads - 1) / kThreads, 1024));
   if (nblocks) *nblocks = main_blocks + fix_blocks;
   // R-MAT 2^28 entries, x = 134 MB: 3.96 -> 3.54 ms with the matrix stream nontemporal (fewer x gathers miss)
+  const int *colv = A->col;
+  const double *xg = x;
+  if (A->col2) {   // columns renumbered hot-first: xg[j] = x[order[j]], then the same product through col2
+    hipLaunchKernelGGL(gather_x_kernel, dim3((unsigned)std::min<int64_t>((A->ncols + 255) / 256, 8192)), dim3(256), 0, c.stream,
+                       A->ncols, A->xorder, x, A->xg, done);
+    colv = A->col2;
+    xg = A->xg;
+  }
   if (nt_matrix((double)A->nnz * 12.0)) {
-    hipLaunchKernelGGL((spmv_split_kernel<MODE, true>), dim3(main_blocks), dim3(kThreads), 0, c.stream, A->nrows, A->nnz, A->rowptr, A->col,
-                       A->val, A->chunk_row, A->nchunks, x, y, alpha, beta, A->carry, slab, done);
+    hipLaunchKernelGGL((spmv_split_kernel<MODE, true>), dim3(main_blocks), dim3(kThreads), 0, c.stream, A->nrows, A->nnz, A->rowptr, colv,
+                       A->val, A->chunk_row, A->nchunks, x, y, alpha, beta, A->carry, slab, done, xg);
   } else {
-    hipLaunchKernelGGL((spmv_split_kernel<MODE, false>), dim3(main_blocks), dim3(kThreads), 0, c.stream, A->nrows, A->nnz, A->rowptr, A->col,
-                       A->val, A->chunk_row, A->nchunks, x, y, alpha, beta, A->carry, slab, done);
+    hipLaunchKernelGGL((spmv_split_kernel<MODE, false>), dim3(main_blocks), dim3(kThreads), 0, c.stream, A->nrows, A->nnz, A->rowptr, colv,
+                       A->val, A->chunk_row, A->nchunks, x, y, alpha, beta, A->carry, slab, done, xg);
   }
   hipLaunchKernelGGL((split_fixup_kernel<MODE>), dim3(fix_blocks), dim3(kThreads), 0, c.stream, A->nrows, A->nnz, A->rowptr,
                      A->chunk_row, A->nchunks, x, y, alpha, beta, A->carry, slab ? slab + main_blocks : nullptr, done);

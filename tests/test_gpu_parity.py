@@ -559,6 +559,37 @@ def test_spmv_split_kernel_large_matrix_stream():
     assert abs(ytx - ref @ xh) <= 1e-12 * (mag @ np.abs(xh))
 
 
+def test_spmv_split_kernel_column_relabelling_is_bit_identical():
+    """power-law matrices whose x outgrows the caches get their columns renumbered hot-first (x is gathered into
+    that order once per product): same pairs in the same order, so the bits must not change.  The size threshold
+    is lowered in a child process (read once); the parent computes the same products without relabelling."""
+    import hashlib, subprocess, sys
+    code = (
+        "import hashlib, numpy as np, iterative_solvers_amd as mk, oracle\n"
+        "r, c, v = oracle.rmat_coo(14, 1 << 18, seed=5)\n"
+        "n = 1 << 14\n"
+        "A = mk.Matrix.from_coo(n, n, r, c, v)\n"
+        "assert A.info().kernel == mk.SPMV_SPLIT\n"
+        "xh = np.random.default_rng(6).normal(size=n)\n"
+        "yh = np.random.default_rng(7).normal(size=n)\n"
+        "x, y = mk.Vector(n, values=xh), mk.Vector(n, values=yh)\n"
+        "h = hashlib.sha1()\n"
+        "A.spmv(x, y, -0.5, 2.0); h.update(y.get().tobytes())\n"
+        "A.spmv(x, y); h.update(y.get().tobytes())\n"
+        "yx, xx = A.spmv_dot(x, y); h.update(y.get().tobytes()); h.update(np.array([yx, xx]).tobytes())\n"
+        "rp, ci, val = A.to_csr()\n"
+        "orp, oci, oval = oracle.coo_to_csr(n, r, c, v)\n"
+        "assert np.array_equal(ci, oci) and np.array_equal(rp, orp)\n"   # get_csr still returns the original numbering
+        "print('HASH', h.hexdigest())\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for tag, extra in (("plain", {"MK_NO_COLUMN_RELABEL": "1"}), ("relabelled", {"MK_RELABEL_MIN_COLS": "1000"})):
+        o = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PYTHONPATH=root, **extra), capture_output=True, text=True, timeout=110)
+        assert o.returncode == 0 and "HASH" in o.stdout, (tag, o.stdout[-300:], o.stderr[-2000:])
+        out[tag] = o.stdout.split("HASH")[1].split()[0]
+    assert out["plain"] == out["relabelled"]
+
+
 def test_spmv_split_fused_dot_square():
     scale, ne = 13, 1 << 18
     r, c, v = oracle.rmat_coo(scale, ne, seed=3)
