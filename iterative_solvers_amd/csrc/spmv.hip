@@ -1562,7 +1562,7 @@ static int prepare_split(mk_matrix *A) {
   static const int64_t min_cols = getenv("MK_RELABEL_MIN_COLS") ? atoll(getenv("MK_RELABEL_MIN_COLS")) : (int64_t)6 << 20;
   if (!A->relabel_tried && !no_relabel && A->ncols >= min_cols && A->nnz >= 4 * A->ncols) {
     A->relabel_tried = 1;
-    MK_TRY(build_column_relabel(A));
+    (void)build_column_relabel(A);   // an optimisation only: on failure (memory) the product stays on the original numbering
   }
   A->relabel_tried = 1;
   if (A->chunk_row) return MK_OK;
