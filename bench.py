@@ -3,19 +3,29 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
 
-One "step" = one CG iteration (K1 SpMV+dots, K2 x/r update+dots, K3 direction update).
-Default workload, the same at every N (strong scaling): the configuration BASELINE.json's
-metric and target are quoted on -- CG on the 3D 7-point Laplacian 512^3 (134M rows, 938M
-entries, fp64, b = 1, x0 = 0), matrix generated in HBM (synthetic); it fits one MI355X.
-At N=1 the line also carries BASELINE.json configs[1] (256^3, Jacobi-PCG) under "secondary".
-Prints ONE JSON line (rank 0).  The timed region starts with everything resident in HBM.
+One "step" = one CG iteration.  Default workload, the same at every N (strong scaling): the configuration
+BASELINE.json's metric and target are quoted on -- CG on the 3D 7-point Laplacian 512^3 (134M rows, 938M entries,
+fp64, b = 1, x0 = 0), matrix generated in HBM (synthetic); it fits one MI355X.  Prints ONE JSON line (rank 0).
+The timed region starts with everything resident in HBM.
 
-For N>1 the driver starts one rank per GPU through torch.distributed.run; torch is used
-for the rendezvous/barrier only, the solve runs inside libmi355_krylov.so.
+At N = 1 the line also carries
+  * `roofline`: the dominant kernel of a CG loop that reads the CSR arrays -- the same grid with VARIABLE coefficients
+    (D A D, every row its own values, like the authors' SuiteSparse inputs), priced on SURVEY.md 8(d)'s bytes
+    12 nnz + 20 n + 4, its duration taken by HIP events inside the solve loop (mk_pcg_set_kernel_timing);
+  * `roofline_value_loop`: the kernels of the loop `value` times (constant coefficients: the two sweeps of the fused
+    step, which read a 2-byte pattern id per row instead of the CSR arrays), priced on THEIR bytes;
+  * `secondary`: BASELINE.json configs[1] (256^3 Jacobi-PCG) and configs[2] (R-MAT scale 24: COO->CSR + SpMV);
+  * `cpu_baseline`: the oracle's OpenMP CG on the full 512^3 operator on the host cores.
+
+For N > 1 the driver starts one rank per GPU through torch.distributed.run; started plainly (`python bench.py --gpus N`,
+no WORLD_SIZE in the environment) this script starts the N ranks itself.  torch is used for the rendezvous/barrier
+only, the solve runs inside libmi355_krylov.so.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,38 +34,110 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (a float4 copy measures 6.29)
 
 WORKLOADS = {
-    # name: (kind, nx, ny, nz, precond, description)
-    "lap7_256_jacobi_pcg": (7, 256, 256, 256, 1, "3D 7-pt Laplacian 256^3, Jacobi-preconditioned CG, fp64"),
-    "lap7_512_cg": (7, 512, 512, 512, 0, "3D 7-pt Laplacian 512^3, CG, fp64 (north-star scaling target)"),
-    "poisson5_1024_cg": (5, 1024, 1024, 1, 0, "2D 5-pt Poisson 1024^2, CG, fp64"),
-    "lap27_256_cg": (27, 256, 256, 256, 0, "3D 27-pt stencil 256^3, CG, fp64"),
+    # name: (kind, nx, ny, nz, precond, scale_seed, description)
+    "lap7_256_jacobi_pcg": (7, 256, 256, 256, 1, None, "3D 7-pt Laplacian 256^3, Jacobi-preconditioned CG, fp64"),
+    "lap7_512_cg": (7, 512, 512, 512, 0, None, "3D 7-pt Laplacian 512^3, CG, fp64 (north-star scaling target)"),
+    "lap7_512_var_cg": (7, 512, 512, 512, 0, 1, "3D 7-pt operator 512^3 with variable coefficients (D A D, per-row scale), CG, fp64"),
+    "lap7_256_var_jacobi_pcg": (7, 256, 256, 256, 1, 1, "3D 7-pt operator 256^3 with variable coefficients, Jacobi-preconditioned CG, fp64"),
+    "poisson5_1024_cg": (5, 1024, 1024, 1, 0, None, "2D 5-pt Poisson 1024^2, CG, fp64"),
+    "lap27_256_cg": (27, 256, 256, 256, 0, None, "3D 27-pt stencil 256^3, CG, fp64"),
     # BASELINE configs[3]; 3.6 G entries: row blocks only (--gpus >= 2), one matrix's int32 row pointers cannot hold it
-    "lap27_512_cg": (27, 512, 512, 512, 0, "3D 27-pt stencil 512^3, CG, fp64, row-block partitioned"),
+    "lap27_512_cg": (27, 512, 512, 512, 0, None, "3D 27-pt stencil 512^3, CG, fp64, row-block partitioned"),
 }
+KERNEL_NAMES = {1: "vector", 2: "stream", 3: "split", 4: "pattern", 5: "sweep", 6: "vsweep"}
+
+
+def host_cpu():
+    """model name and physical core count of the box (the reference's job scripts print lscpu: scripts/job_gpu:114-116)"""
+    model, cores = "unknown", set()
+    try:
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name":
+                model = v
+            elif k == "physical id":
+                phys = v
+            elif k == "core id":
+                core = v
+            elif not k and phys is not None:
+                cores.add((phys, core))
+                phys = core = None
+        if phys is not None:
+            cores.add((phys, core))
+    except OSError:
+        pass
+    return model, len(cores)
 
 
 def cpu_baseline(kind, nx, ny, nz, precond, iters):
-    """the oracle's OpenMP CG on the host cores, bounded sample of the same workload: a z-slab
-    of at most 64 planes of the same operator; the rate is scaled to the full row count"""
+    """the oracle's OpenMP CG (oracle/oracle.c orc_pcg, the CPU restatement of the hypre loop) on the FULL operator of
+    the headline workload, `iters` iterations after a 2-iteration warm-up; threads = what OpenMP finds on this box"""
     import oracle
     t0 = time.time()
-    nz_s = min(nz, 64)
-    rp, ci, v = oracle.stencil_csr(kind, nx, ny, nz_s)
+    rp, ci, v = oracle.stencil_csr(kind, nx, ny, nz)
     n = rp.size - 1
     b = np.ones(n)
     oracle.pcg(rp, ci, v, b, precond=precond, tol=0.0, maxit=2, omp=True)   # page-in / warm-up
     t1 = time.time()
     o = oracle.pcg(rp, ci, v, b, precond=precond, tol=0.0, maxit=iters, omp=True)
     dt = time.time() - t1
-    cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
-    frac = nz_s / nz
-    return {"value": round(o["iterations"] / dt * frac, 3), "unit": "CG iterations/s", "cores": cores, "kind": "port",
-            "sample": f"{iters} CG iterations on a {nx}x{ny}x{nz_s} slab of the same operator ({frac:.3f} of the rows; "
-                      f"measured {o['iterations'] / dt:.2f} it/s on the slab, scaled by {frac:.3f}); oracle/oracle.c orc_pcg, "
-                      f"OpenMP; setup {t1 - t0:.1f}s excluded"}
+    model, phys = host_cpu()
+    threads = oracle.num_threads()
+    return {"value": round(o["iterations"] / dt, 3), "unit": "CG iterations/s", "cores": threads, "kind": "port",
+            "cpu_model": model, "physical_cores_of_the_machine": phys,
+            "sample": f"{o['iterations']} CG iterations on the full {nx}x{ny}x{nz} operator ({n} rows, {rp[-1]} entries; the first "
+                      f"{o['iterations']} of the iterations the GPU times), {dt:.1f} s; oracle/oracle.c orc_pcg, OpenMP with {threads} "
+                      f"threads (OMP_NUM_THREADS={os.environ.get('OMP_NUM_THREADS', 'unset')}, OMP_PROC_BIND="
+                      f"{os.environ.get('OMP_PROC_BIND', 'unset')}); matrix generation + warm-up {t1 - t0:.1f} s not counted"}
+
+
+# ------------------------------------------------------------------------------ starting the ranks ourselves
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(ngpus, argv):
+    """`python bench.py --gpus N` without a launcher: this parent (which never touches the GPU) starts N children of the
+    same script with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, relays rank 0's line, and returns the worst exit code"""
+    port = _free_port()
+    procs = []
+    for r in range(ngpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(ngpus), LOCAL_WORLD_SIZE=str(ngpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        rc = max(rc, abs(p.wait()))
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    return rc
+
+
+def dry_run_rank(args, rank, world):
+    """MK_BENCH_DRY_SPAWN=1: rehearsal of the launch logic on CPU (gloo): rendezvous, id broadcast, barrier, one line"""
+    import torch
+    import torch.distributed as dist
+    from iterative_solvers_amd import distributed as mkd
+    dist.init_process_group("gloo")
+    ident = mkd.broadcast_bytes(bytes(range(256)) if rank == 0 else None, 256, 0)
+    t = torch.tensor([float(rank)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "max_rank": t.item(), "id_ok": ident == bytes(range(256)),
+                          "steps": args.steps, "warmup": args.warmup}), flush=True)
+    dist.destroy_process_group()
 
 
 def main():
@@ -65,8 +147,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-iters", type=int, default=20)
+    ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--cpu-iters", type=int, default=10)
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -74,7 +160,9 @@ def main():
         local_rank = int(os.environ["MK_BENCH_DEVICE"])
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch through torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if os.environ.get("MK_BENCH_DRY_SPAWN"):
+        return dry_run_rank(args, rank, world)
 
     import torch
     import torch.distributed as dist
@@ -90,14 +178,23 @@ def main():
         from iterative_solvers_amd import distributed as mkd
         return mkd.bench_main(args, rank, local_rank, world, WORKLOADS, HBM_PEAK_GBS)
 
-    def measure(name, steps, warmup):
-        kind, nx, ny, nz, precond, desc = WORKLOADS[name]
-        A = mk.Matrix.stencil(kind, nx, ny, nz)
+    traffic_db = {}
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        traffic_db = json.load(open(tpath))
+
+    def measure(name, steps, warmup, timing=True):
+        """CG on workload `name`: a warm-up solve, the timed solve (wall clock around mk_pcg_solve, stream drained on
+        both sides), then one more solve with HIP events around every kernel of iterations 2..33"""
+        kind, nx, ny, nz, precond, seed, desc = WORKLOADS[name]
+        A = mk.Matrix.stencil(kind, nx, ny, nz, scale_seed=seed)
         n = A.nrows
         b, x = mk.Vector(n, fill=1.0), mk.Vector(n, fill=0.0)
 
-        def run(iters):
+        def run(iters, timed_kernels=False):
             S = mk.PCG(max_iter=iters, tol=0.0, two_norm=1, rel_change=1, precond=precond, logging=0, check_every=50)
+            if timed_kernels:
+                S.set_kernel_timing(True)
             S.setup(A, b, x)
             x.fill(0.0)
             mk.synchronize()
@@ -108,88 +205,149 @@ def main():
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
             assert res["iterations"] == iters, res
-            return dt, res
+            return dt, res, (S.kernel_timing() if timed_kernels else None)
 
         run(max(warmup, 1))
-        dt, res = run(steps)
-        return A, b, dt, res
+        dt, res, _ = run(steps)
+        kt = run(34, True)[2] if timing else None
+        return A, dt, res, kt
+
+    def kernel_blocks(name, A, kt):
+        """one roofline block per kernel slot of the CG step, from the in-loop HIP-event averages"""
+        info = A.info()
+        n, nnz = A.nrows, A.nnz
+        precond = WORKLOADS[name][4]
+        kname = KERNEL_NAMES.get(info.kernel, str(info.kernel))
+        csr = 12 * nnz + 20 * n + 4           # SURVEY.md 8(d)
+        fused = info.kernel == 5 and not os.environ.get("MK_NO_FUSED_CG")
+        if fused:
+            # fused step on sweep matrices (DESIGN 4.2): first sweep p' = z + beta p and the dots of A p' (2 + 8 + 8 + 8 B/row),
+            # second sweep r -= alpha A p' recomputed, x += alpha p' (2 + 8 + 16 + 16 B/row); K3 rides in the first
+            slots = [("spmv_sweep_kernel MODE 5 (p' = z + beta p in the window fill, dots of A p')", 26 * n, "26 B/row: 2 B pattern id, r 8, p 8, p' 8"),
+                     ("spmv_sweep_kernel MODE 4 (r -= alpha A p recomputed, x += alpha p, dots)", 42 * n, "42 B/row: 2 B pattern id, p 8, r 8 + 8, x 8 + 8")]
+            if kt is not None and len(kt) == 3:
+                slots.append(("pcg_update_p_kernel (K3)", 24 * n, "24 B/row"))
+        else:
+            own = csr if info.kernel in (1, 2, 3, 6) else 18 * n + 4
+            slots = [(f"spmv+dot, {kname} kernel (K1: s = A p, <s,p>, <p,p>)", own,
+                      "SURVEY 8(d): 12 nnz + 20 n + 4" if own == csr else "18 B/row: 2 B pattern id + 8 B x + 8 B y"),
+                     ("pcg_update_xr_kernel (K2)", (56 if precond else 48) * n, "x, r read+write, p, s read" + (", 1/diag" if precond else "")),
+                     ("pcg_update_p_kernel (K3)", (32 if precond else 24) * n, "r, p read, p write" + (", 1/diag" if precond else ""))]
+        out = []
+        for k, (label, nbytes, model) in enumerate(slots):
+            ms, cnt = (kt[k] if kt is not None and k < len(kt) else (0.0, 0))
+            gbps = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else None
+            tr = traffic_db.get(f"{name}:slot{k}")
+            out.append({"kernel": label, "bound": "hbm", "achieved": round(gbps, 1) if gbps else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(gbps / HBM_PEAK_GBS, 4) if gbps else None, "bytes_per_launch": nbytes, "bytes_model": model,
+                        "avg_launch_ms": round(ms, 5), "launches_timed": cnt, "traffic": tr,
+                        "traffic_frac": round(tr / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if tr and ms > 0 else None})
+        return out, kname, csr
 
     name = args.workload or "lap7_512_cg"
-    kind, nx, ny, nz, precond, desc = WORKLOADS[name]
-    A, b, dt, res = measure(name, args.steps, args.warmup)
+    kind, nx, ny, nz, precond, seed, desc = WORKLOADS[name]
+    A, dt, res, kt = measure(name, args.steps, args.warmup)
     n, nnz = A.nrows, A.nnz
     info = A.info()
     ms_per_step = dt * 1e3 / args.steps
-    iters_per_s = args.steps / dt
-
-    # dominant kernel: the fused SpMV (+<s,p>,<p,p>) launch, timed alone with HIP events on
-    # the library's own stream
-    s = mk.Vector(n)
-    reps = 50
-    for _ in range(5):
-        A.spmv_dot(b, s, want=False)
-    mk.timer_start()
-    for _ in range(reps):
-        A.spmv_dot(b, s, want=False)
-    spmv_ms = mk.timer_stop() / reps
-    kname = {1: "vector", 2: "stream", 3: "split", 4: "pattern", 5: "sweep"}.get(info.kernel, str(info.kernel))
-    csr_bytes = 12 * nnz + 20 * n + 4           # val 8 + col 4 per entry, rowptr 4 + x 8 + y 8 per row
-    # the pattern and sweep kernels (rows drawn from a table of (offsets, values) patterns) read none of the CSR
-    # arrays: its algorithmic bytes are the 2-byte pattern id, x and y per row.  The roofline is priced
-    # on what the kernel that ran has to move; the CSR-model rate is reported beside it.
-    spmv_bytes = 18 * n + 4 if info.kernel in (4, 5) else csr_bytes
-    achieved = spmv_bytes / (spmv_ms * 1e-3) / 1e9
-    vec_bytes = (88 if precond else 72) * n     # K2 + K3: x, p, r, s (and 1/diag) streams
-    iter_bytes = spmv_bytes + vec_bytes
-    if info.kernel == 5 and not os.environ.get("MK_NO_FUSED_CG"):
-        # fused step on sweep matrices: first sweep p' = z + beta p, dots of A p' (2 + 8 + 8 + 8 B/row), second sweep
-        # r -= alpha A p' recomputed, x += alpha p' (2 + 8 + 16 + 16); 1/diag is one number on these operators
-        iter_bytes = 68 * n
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
-        traffic = json.load(open(tpath)).get(name + ":" + kname)
-
+    blocks, kname, csr_bytes = kernel_blocks(name, A, kt)
+    vec_bytes = (88 if precond else 72) * n
+    own_iter_bytes = sum(b["bytes_per_launch"] for b in blocks)
     out = {
         "metric": "CG iterations/s (fp64, fused SpMV+dot+axpy) with SpMV effective HBM GB/s",
-        "value": round(iters_per_s, 2), "unit": "CG iterations/s", "n_gpus": 1, "steps": args.steps,
+        "value": round(args.steps / dt, 2), "unit": "CG iterations/s", "n_gpus": 1, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": desc, "name": name, "rows": n, "nnz": nnz, "precond": "jacobi" if precond else "none",
                    "spmv_kernel": kname, "index_patterns": info.index_patterns, "value_patterns": info.value_patterns,
                    "parallelism": "1 GPU"},
-        "iteration_effective_GBps": round(iter_bytes / (ms_per_step * 1e-3) / 1e9, 1),
-        "iteration_csr_model_GBps": round((csr_bytes + vec_bytes) / (ms_per_step * 1e-3) / 1e9, 1),
-        "roofline": {"bound": "hbm", "kernel": "spmv+dot (K1, %s kernel)" % kname, "achieved": round(achieved, 1),
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                     "bytes_per_launch": spmv_bytes, "avg_launch_ms": round(spmv_ms, 5),
-                     "bytes_model": ("18 B/row: 2 B pattern id + 8 B x + 8 B y (what the pattern/sweep kernels read and write)"
-                                     if info.kernel in (4, 5) else "SURVEY 8(d): 12 nnz + 20 n + 4"),
-                     # the north star counts values + column indices + row pointers + x/y; priced that
-                     # way a launch that reads 2 B of matrix data per row exceeds the peak by construction
-                     "csr_model_bytes": csr_bytes, "csr_model_GBps": round(csr_bytes / (spmv_ms * 1e-3) / 1e9, 1),
-                     "csr_model_frac": round(csr_bytes / (spmv_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
         "final_rel_res_norm": res["rel_res_norm"],
+        # the loop `value` times, kernel by kernel, on the bytes those kernels move (NOT the CSR model: on constant-
+        # coefficient grids they read a 2-byte pattern id per row and none of the CSR arrays)
+        "roofline_value_loop": {"note": "kernels of the timed CG loop, durations by HIP events inside mk_pcg_solve "
+                                        "(iterations 2..33 of a separate 34-iteration solve on the same stream)",
+                                "kernels": blocks,
+                                "iteration": {"bytes": own_iter_bytes, "achieved": round(own_iter_bytes / (ms_per_step * 1e-3) / 1e9, 1),
+                                              "frac": round(own_iter_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                              "traffic": traffic_db.get(f"{name}:iteration"),
+                                              "csr_model_bytes": csr_bytes + vec_bytes,
+                                              "csr_model_GBps": round((csr_bytes + vec_bytes) / (ms_per_step * 1e-3) / 1e9, 1)}},
     }
-    # the timed region itself: one CG iteration = its kernels back to back (two sweeps on the fused path), priced on
-    # the bytes they move; `traffic` is the PMC sum over the kernels of one iteration (profiles/traffic.json)
-    it_traffic = None
-    if os.path.exists(tpath):
-        it_traffic = json.load(open(tpath)).get(name + ":" + kname + ":iteration")
-    it_gbps = iter_bytes / (ms_per_step * 1e-3) / 1e9
-    out["roofline_iteration"] = {"bound": "hbm", "kernel": "whole CG iteration (timed region of `value`)", "achieved": round(it_gbps, 1),
-                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(it_gbps / HBM_PEAK_GBS, 4),
-                                 "bytes_per_iteration": iter_bytes, "traffic": it_traffic}
-    del A, b, s
-    if args.workload is None:
-        # BASELINE.json configs[1] beside the headline: 256^3, Jacobi-preconditioned CG, one GPU
-        sname = "lap7_256_jacobi_pcg"
-        A2, b2, dt2, res2 = measure(sname, args.steps, args.warmup)
-        out["secondary"] = {sname: {"workload": WORKLOADS[sname][5], "value": round(args.steps / dt2, 2),
-                                    "unit": "CG iterations/s", "ms_per_step": round(dt2 * 1e3 / args.steps, 4),
-                                    "spmv_kernel": {1: "vector", 2: "stream", 3: "split", 4: "pattern", 5: "sweep"}.get(A2.info().kernel),
-                                    "iteration_csr_model_GBps": round((12 * A2.nnz + 108 * A2.nrows) / (dt2 / args.steps) / 1e9, 1)}}
-        del A2, b2
+    del A
+
+    # ---- the roofline of the line: a CG loop whose dominant kernel reads the CSR value array.  Same grid, variable
+    # coefficients (unless the workload asked for already is one).
+    vname = name if seed is not None else ("lap7_512_var_cg" if (kind, nx, ny, nz) == (7, 512, 512, 512) else None)
+    if vname is not None:
+        if vname == name:
+            vblocks, vk, vcsr, vdt, vn, vnnz, vinfo = blocks, kname, csr_bytes, dt, n, nnz, info
+        else:
+            A2, vdt, vres, vkt = measure(vname, args.steps, args.warmup)
+            vblocks, vk, vcsr = kernel_blocks(vname, A2, vkt)
+            vn, vnnz, vinfo = A2.nrows, A2.nnz, A2.info()
+            del A2
+        k1 = vblocks[0]
+        vms = vdt * 1e3 / args.steps
+        vprec = WORKLOADS[vname][4]
+        viter = vcsr + (88 if vprec else 72) * vn      # SURVEY 8(d): 12 nnz + 92 n (+16 n with Jacobi)
+        out["roofline"] = {
+            "bound": "hbm", "workload": WORKLOADS[vname][6], "name": vname,
+            "kernel": k1["kernel"] + " -- the dominant kernel of the CG loop on this operator; reads val[] (8 B/entry), "
+                      "a 2-byte column-pattern id per row in place of col[] (lossless), row pointers, x; writes y",
+            "achieved": k1["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": k1["frac"],
+            "bytes_per_launch": vcsr, "bytes_model": "SURVEY 8(d): 12 nnz + 20 n + 4 (values + column indices + row pointers + x/y)",
+            "avg_launch_ms": k1["avg_launch_ms"], "launches_timed": k1["launches_timed"],
+            "measured": "HIP events around the kernel inside mk_pcg_solve, on the library's stream",
+            "traffic": k1["traffic"], "traffic_frac": k1["traffic_frac"],
+            "target_0_75_met": bool(k1["frac"] is not None and k1["frac"] >= 0.75),
+            "index_patterns": vinfo.index_patterns, "value_patterns": vinfo.value_patterns,
+            "cg": {"value": round(args.steps / vdt, 2), "unit": "CG iterations/s", "ms_per_step": round(vms, 4),
+                   "iteration_bytes": viter, "iteration_GBps": round(viter / (vms * 1e-3) / 1e9, 1),
+                   "iteration_frac": round(viter / (vms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "kernels": vblocks},
+        }
+    else:
+        k1 = blocks[0]
+        out["roofline"] = {"bound": "hbm", "kernel": k1["kernel"], "achieved": k1["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": k1["frac"], "traffic": k1["traffic"], "bytes_per_launch": k1["bytes_per_launch"],
+                           "bytes_model": k1["bytes_model"], "avg_launch_ms": k1["avg_launch_ms"]}
+
+    if args.workload is None and not args.no_secondary:
+        sec = {}
+        # BASELINE.json configs[1]: 256^3, Jacobi-preconditioned CG, one GPU -- constant and variable coefficients
+        for sname in ("lap7_256_jacobi_pcg", "lap7_256_var_jacobi_pcg"):
+            A2, dt2, res2, kt2 = measure(sname, args.steps, args.warmup)
+            b2, k2, csr2 = kernel_blocks(sname, A2, kt2)
+            sec[sname] = {"workload": WORKLOADS[sname][6], "value": round(args.steps / dt2, 2), "unit": "CG iterations/s",
+                          "ms_per_step": round(dt2 * 1e3 / args.steps, 4), "spmv_kernel": k2,
+                          "iteration_csr_model_GBps": round((12 * A2.nnz + 108 * A2.nrows) / (dt2 / args.steps) / 1e9, 1),
+                          "kernel_ms": [b["avg_launch_ms"] for b in b2]}
+            del A2
+        # BASELINE.json configs[2]: R-MAT scale 24, 2^28 edges: COO -> CSR on the device, then SpMV (split kernel)
+        try:
+            scale, ne = 24, 1 << 28
+            coo = mk.DeviceCOO.rmat(scale, ne, seed=42)
+            mk.synchronize()
+            mk.timer_start()
+            A3 = mk.Matrix.from_device_coo(coo)
+            conv_ms = mk.timer_stop()
+            n3, nnz3 = A3.nrows, A3.nnz
+            x3, y3 = mk.Vector(n3, fill=1.0), mk.Vector(n3)
+            for _ in range(3):
+                A3.spmv(x3, y3)
+            mk.timer_start()
+            for _ in range(10):
+                A3.spmv(x3, y3)
+            spmv_ms = mk.timer_stop() / 10
+            cbytes, sbytes = 32 * nnz3 + 12 * n3, 12 * nnz3 + 20 * n3 + 4
+            sec["rmat_s24"] = {"workload": "R-MAT scale 24, 2^28 edges (a,b,c = 0.57,0.19,0.19; duplicates kept): COO->CSR + SpMV",
+                               "coo_to_csr_ms": round(conv_ms, 3), "coo_to_csr_frac": round(cbytes / (conv_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                               "coo_to_csr_bytes_model": "SURVEY 8(d): 32 nnz + 12 n",
+                               "spmv_ms": round(spmv_ms, 4), "spmv_frac": round(sbytes / (spmv_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                               "spmv_kernel": KERNEL_NAMES.get(A3.info().kernel), "max_row_len": A3.info().max_row_len}
+            del A3, x3, y3, coo
+        except mk.MkError as e:      # never lose the headline to a secondary measurement
+            sec["rmat_s24"] = {"error": str(e)}
+        out["secondary"] = sec
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(kind, nx, ny, nz, precond, args.cpu_iters)
     print(json.dumps(out), flush=True)

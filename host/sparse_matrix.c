@@ -309,19 +309,37 @@ int write_stencil_mtx(const char *path, int kind, int nx, int ny, int nz) {
 /* ---- binary CSR cache: the converted matrix beside the .mtx, so that a second
  * run skips both the text parse and the sort.  Layout: 64-byte header, then row_pointers
  * (int32[nrows+1]), column_indices (int32[nnz]), values (f64[nnz]), each padded to 64 bytes.
- * No reference counterpart. */
+ * The header remembers size and modification time of the text file the cache was made from:
+ * read_csr_cache_for() refuses a cache whose source has changed since.  No reference counterpart. */
+#include <sys/stat.h>
+
 typedef struct {
-  char magic[8];            /* "MKCSR01\0" */
+  char magic[8];            /* "MKCSR02\0" */
   unsigned int nrows, ncolumns, nnz, endian_mark;
-  unsigned long long checksum;   /* sum of all row pointers and column indices, wrap-around */
-  char pad[32];
+  unsigned long long checksum;   /* wrap-around sum over row pointers, column indices and the value words */
+  unsigned long long src_size;   /* bytes of the source .mtx, 0 = not recorded */
+  long long src_mtime_ns;        /* its modification time */
+  char pad[16];
 } csr_cache_header;
 
 static unsigned long long csr_checksum(const SparseMatrixCSR *m) {
   unsigned long long s = 0;
   for (unsigned int i = 0; i <= m->nrows; i++) s += (unsigned int)m->row_pointers[i];
   for (unsigned int k = 0; k < m->nnz; k++) s += (unsigned int)m->column_indices[k];
+  for (unsigned int k = 0; k < m->nnz; k++) {   /* the values as 64-bit words, position-weighted so that swaps show */
+    unsigned long long w;
+    memcpy(&w, &m->values[k], sizeof w);
+    s += w * (2ull * k + 1ull);
+  }
   return s;
+}
+
+static int source_stamp(const char *src, unsigned long long *size, long long *mtime_ns) {
+  struct stat st;
+  if (!src || stat(src, &st) != 0) return 1;
+  *size = (unsigned long long)st.st_size;
+  *mtime_ns = (long long)st.st_mtim.tv_sec * 1000000000ll + (long long)st.st_mtim.tv_nsec;
+  return 0;
 }
 
 static int write_padded(FILE *f, const void *p, size_t bytes) {
@@ -331,14 +349,16 @@ static int write_padded(FILE *f, const void *p, size_t bytes) {
   return padn && fwrite(zeros, 1, padn, f) != padn;
 }
 
-int write_csr_cache(const char *path, const SparseMatrixCSR *m) {
+/* src may be NULL (no source recorded: the cache is then accepted for any source) */
+int write_csr_cache_for(const char *path, const SparseMatrixCSR *m, const char *src) {
   FILE *f = fopen(path, "wb");
   if (!f) return 1;
   csr_cache_header h;
   memset(&h, 0, sizeof h);
-  memcpy(h.magic, "MKCSR01", 8);
+  memcpy(h.magic, "MKCSR02", 8);
   h.nrows = m->nrows; h.ncolumns = m->ncolumns; h.nnz = m->nnz; h.endian_mark = 0x01020304u;
   h.checksum = csr_checksum(m);
+  if (src && source_stamp(src, &h.src_size, &h.src_mtime_ns) != 0) { h.src_size = 0; h.src_mtime_ns = 0; }
   int bad = fwrite(&h, sizeof h, 1, f) != 1;
   bad = bad || write_padded(f, m->row_pointers, ((size_t)m->nrows + 1) * sizeof(int));
   bad = bad || write_padded(f, m->column_indices, (size_t)m->nnz * sizeof(int));
@@ -348,19 +368,27 @@ int write_csr_cache(const char *path, const SparseMatrixCSR *m) {
   return bad;
 }
 
+int write_csr_cache(const char *path, const SparseMatrixCSR *m) { return write_csr_cache_for(path, m, NULL); }
+
 static int read_padded(FILE *f, void *p, size_t bytes) {
   if (bytes && fread(p, 1, bytes, f) != bytes) return 1;
   const long padn = (long)((64 - bytes % 64) % 64);
   return padn && fseek(f, padn, SEEK_CUR) != 0;
 }
 
-/* returns 0 and fills *m (aligned_alloc'ed arrays), or non-zero when the file is absent, short,
- * from another byte order, or fails its checksum */
-int read_csr_cache(const char *path, SparseMatrixCSR *m) {
+/* returns 0 and fills *m (aligned_alloc'ed arrays), or non-zero when the file is absent (1), short, from
+ * another byte order or format version (2), fails its checksum (3), or was made from a source file whose
+ * size or modification time differs from src's now (4; only when src is given and the cache recorded one) */
+int read_csr_cache_for(const char *path, SparseMatrixCSR *m, const char *src) {
   FILE *f = fopen(path, "rb");
   if (!f) return 1;
   csr_cache_header h;
-  if (fread(&h, sizeof h, 1, f) != 1 || memcmp(h.magic, "MKCSR01", 8) != 0 || h.endian_mark != 0x01020304u) { fclose(f); return 2; }
+  if (fread(&h, sizeof h, 1, f) != 1 || memcmp(h.magic, "MKCSR02", 8) != 0 || h.endian_mark != 0x01020304u) { fclose(f); return 2; }
+  if (src && h.src_size != 0) {
+    unsigned long long size = 0;
+    long long mtime_ns = 0;
+    if (source_stamp(src, &size, &mtime_ns) != 0 || size != h.src_size || mtime_ns != h.src_mtime_ns) { fclose(f); return 4; }
+  }
   m->nrows = h.nrows; m->ncolumns = h.ncolumns; m->nnz = h.nnz;
   m->row_pointers = (int *)aalloc(((size_t)h.nrows + 1) * sizeof(int));
   m->column_indices = (int *)aalloc((size_t)h.nnz * sizeof(int));
@@ -372,5 +400,46 @@ int read_csr_cache(const char *path, SparseMatrixCSR *m) {
   fclose(f);
   if (!bad) bad = (m->row_pointers[0] != 0) || ((unsigned int)m->row_pointers[h.nrows] != h.nnz) || (csr_checksum(m) != h.checksum);
   if (bad) { free_csr(m); return 3; }
+  return 0;
+}
+
+int read_csr_cache(const char *path, SparseMatrixCSR *m) { return read_csr_cache_for(path, m, NULL); }
+
+/* ---- row blocks for np > 1 (solvers.c:214-281).  The reference sorts on rank 0, broadcasts the whole COO
+ * and lets every rank pick rows[l_idx..] out of it; here every rank reads the file itself, counts the rows,
+ * asks mk_partition_rows for the cuts and keeps only its own entries. */
+
+/* rowptr[r] = number of entries in rows < r (nrows + 1 values); 1 when an index is out of range */
+int coo_row_pointers64(const SparseMatrixCOO *coo, long long *rowptr) {
+  memset(rowptr, 0, ((size_t)coo->nrows + 1) * sizeof(long long));
+  for (unsigned int k = 0; k < coo->nnz; k++) {
+    const int r = coo->rows[k];
+    if (r < 0 || (unsigned int)r >= coo->nrows) return 1;
+    rowptr[r + 1]++;
+  }
+  for (unsigned int r = 0; r < coo->nrows; r++) rowptr[r + 1] += rowptr[r];
+  return 0;
+}
+
+/* the entries of rows [row_lo, row_hi) in input order, rows renumbered from 0, global column ids kept */
+int slice_coo_rows(const SparseMatrixCOO *coo, long long row_lo, long long row_hi, SparseMatrixCOO *out) {
+  if (row_lo < 0 || row_hi < row_lo || row_hi > (long long)coo->nrows) return 1;
+  size_t cnt = 0;
+  for (unsigned int k = 0; k < coo->nnz; k++) cnt += (coo->rows[k] >= row_lo && coo->rows[k] < row_hi);
+  out->nrows = (unsigned int)(row_hi - row_lo);
+  out->ncolumns = coo->ncolumns;
+  out->nnz = (unsigned int)cnt;
+  out->rows = (int *)aalloc(cnt * sizeof(int));
+  out->columns = (int *)aalloc(cnt * sizeof(int));
+  out->values = (double *)aalloc(cnt * sizeof(double));
+  if (!out->rows || !out->columns || !out->values) { free_coo(out); return 2; }
+  size_t j = 0;
+  for (unsigned int k = 0; k < coo->nnz; k++)
+    if (coo->rows[k] >= row_lo && coo->rows[k] < row_hi) {
+      out->rows[j] = (int)(coo->rows[k] - row_lo);
+      out->columns[j] = coo->columns[k];
+      out->values[j] = coo->values[k];
+      j++;
+    }
   return 0;
 }

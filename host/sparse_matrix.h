@@ -28,6 +28,12 @@ size_t get_multiple_of_align_size(size_t size);
 /* binary CSR cache beside the .mtx (extension) */
 int write_csr_cache(const char *path, const SparseMatrixCSR *m);
 int read_csr_cache(const char *path, SparseMatrixCSR *m);
+/* the same, remembering / checking size and modification time of the .mtx the cache was made from */
+int write_csr_cache_for(const char *path, const SparseMatrixCSR *m, const char *src_mtx);
+int read_csr_cache_for(const char *path, SparseMatrixCSR *m, const char *src_mtx);
+/* row blocks for np > 1 (solvers.c:214-281): row pointers of an unsorted COO, and one rank's entries */
+int coo_row_pointers64(const SparseMatrixCOO *coo, long long *rowptr);
+int slice_coo_rows(const SparseMatrixCOO *coo, long long row_lo, long long row_hi, SparseMatrixCOO *out);
 int write_stencil_mtx(const char *path, int kind, int nx, int ny, int nz);   /* synthetic test input */
 #ifdef __cplusplus
 }

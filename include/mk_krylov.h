@@ -136,6 +136,10 @@ int mk_matrix_set_spmv_kernel(mk_matrix *A, int kernel, int lanes_per_row);
 /* kind 5: 2D 5-pt (nz ignored), 7: 3D 7-pt, 27: 3D 27-pt; lexicographic, x fastest.
  * rows [row_begin,row_end) of the global operator, global column ids. */
 int mk_matrix_generate_stencil(int kind, int nx, int ny, int nz, int64_t row_begin, int64_t row_end, mk_matrix **A);
+/* the same operator scaled symmetrically, D A D with d_i in [1, 5) drawn per row from a counter-based hash of
+ * (seed, global row): every row has its own coefficients (the constant-coefficient kernels do not apply, the matrix
+ * is served from its CSR value array like the authors' SuiteSparse inputs), still symmetric positive definite */
+int mk_matrix_generate_stencil_scaled(int kind, int nx, int ny, int nz, uint64_t seed, int64_t row_begin, int64_t row_end, mk_matrix **A);
 int mk_matrix_generate_banded(int64_t n, int half_bandwidth, int64_t row_begin, int64_t row_end, mk_matrix **A);
 /* R-MAT edge list, unsorted, duplicates kept (counter-based splitmix64; oracle/oracle.c holds the same definition) */
 int mk_coo_generate_rmat(int scale, uint64_t nedges, uint64_t seed, double a, double b, double c, mk_coo **coo);
@@ -169,6 +173,12 @@ int mk_pcg_set_print_level(mk_pcg *solver, int level);            /* HYPRE_PCGSe
 int mk_pcg_set_logging(mk_pcg *solver, int logging);              /* HYPRE_PCGSetLogging :744 */
 int mk_pcg_set_precond(mk_pcg *solver, int precond);              /* extension id 51: HYPRE_ParCSRDiagScale semantics */
 int mk_pcg_set_check_every(mk_pcg *solver, int iterations);       /* how often the host reads the device-side stop flag */
+/* measurement hook (bench.py's roofline figures; SURVEY.md 8(d) "hipEvent around the iterations"): with on = 1 the next
+ * mk_pcg_solve records a HIP event in front of every kernel of its iterations 2..33 on the library's stream;
+ * get returns, per kernel slot of a step (0: SpMV + dots, 1: x/r update, 2: direction update when it is a kernel of
+ * its own), the average duration in milliseconds and the number of launches it was taken over (capacity >= 3) */
+int mk_pcg_set_kernel_timing(mk_pcg *solver, int on);
+int mk_pcg_get_kernel_timing(const mk_pcg *solver, int *nslots, double *avg_ms, long long *launches, int capacity);
 int mk_pcg_setup(mk_pcg *solver, const mk_matrix *A, const mk_vector *b, const mk_vector *x);   /* HYPRE_ParCSRPCGSetup :747 */
 int mk_pcg_solve(mk_pcg *solver, const mk_matrix *A, const mk_vector *b, mk_vector *x);         /* HYPRE_ParCSRPCGSolve :754 */
 int mk_pcg_get_num_iterations(const mk_pcg *solver, long long *iterations);                    /* HYPRE_PCGGetNumIterations :765 */
@@ -263,6 +273,9 @@ int mk_comm_create(const void *id256, int nranks, int rank, mk_comm **comm);   /
 int mk_comm_create_local(int nranks, mk_comm **comms);
 /* collective check of every RCCL call the solver relies on (ring send/recv, all-gather, all-reduce) */
 int mk_comm_self_test(mk_comm *comm);
+/* MPI_Allreduce of a few host doubles (solvers.c:760: the solve time, MPI_MAX).  op: 0 sum, 1 max.  Collective;
+ * a local world or a NULL communicator leaves the values as they are. */
+int mk_comm_all_reduce_host(mk_comm *comm, double *values, int count, int op);
 int mk_comm_destroy(mk_comm *comm);
 /* A holds rows [row_start[rank], row_start[rank+1]) of the global operator with GLOBAL column
  * ids (ncols = n_global) and is consumed.  Collective. comm may be NULL for a single rank. */
@@ -283,6 +296,18 @@ int mk_dist_spmv(int nranks_here, mk_dist_matrix **A, mk_vector **x, mk_vector *
 int mk_dist_pcg_solve(int nranks_here, mk_pcg **solvers, mk_dist_matrix **A, mk_vector **b, mk_vector **x);
 /* plain Jacobi (extension id 70) on the distributed operator; residual all-reduced every check_every iterations */
 int mk_dist_jacobi_solve(int nranks_here, mk_jacobi **solvers, mk_dist_matrix **A, mk_vector **b, mk_vector **x);
+
+/* ---- exchange planning, host only (no GPU): the host half of the ParCSR communication package that
+ *      HYPRE_IJMatrixAssemble builds (solvers.c:362); mk_dist_matrix_create runs exactly these -------------- */
+int mk_halo_check_row_start(int nranks, const int64_t *row_start, int64_t n_global);
+/* sorted distinct global column ids outside [row_begin,row_end) of a CSR block with global column ids;
+ * ghosts may be NULL to query the count */
+int mk_halo_ghost_columns(int64_t nrows, const int *rowptr, const int *col, int64_t row_begin, int64_t row_end, int64_t n_global,
+                          int *ghosts, int64_t capacity, int64_t *n_ghost);
+/* per owner rank: how many of the (sorted) ghosts it owns and where their run starts (nranks / nranks + 1 values) */
+int mk_halo_plan_recv(int nranks, int rank, const int64_t *row_start, const int *ghosts, int64_t n_ghost, int *recv_cnt, int *recv_off);
+/* recv_cnt_all[q * nranks + r] = what q receives from r (all-gathered); out: what `rank` sends to each q */
+int mk_halo_plan_send(int nranks, int rank, const int *recv_cnt_all, int *send_cnt, int *send_off);
 
 /* ---- row-block partition: solvers.c:214-231,270-281 with defects Q1-Q4 repaired ----------- */
 /* host-only; rowptr64 has nrows+1 entries; row_start gets nparts+1 entries */

@@ -47,13 +47,13 @@ EXPORTS = [
     "mk_sort_coo_row", "mk_coo_to_csr",
     "mk_matrix_from_coo", "mk_matrix_from_csr", "mk_matrix_from_device_coo", "mk_matrix_destroy",
     "mk_matrix_get_csr", "mk_matrix_get_info", "mk_matrix_set_spmv_kernel",
-    "mk_matrix_generate_stencil", "mk_matrix_generate_banded", "mk_coo_generate_rmat",
+    "mk_matrix_generate_stencil", "mk_matrix_generate_stencil_scaled", "mk_matrix_generate_banded", "mk_coo_generate_rmat",
     "mk_coo_from_host", "mk_coo_download", "mk_coo_destroy",
     "mk_vector_create", "mk_vector_set", "mk_vector_fill", "mk_vector_get", "mk_vector_destroy",
     "mk_vector_size", "mk_spmv", "mk_spmv_dot",
     "mk_pcg_create", "mk_pcg_set_max_iter", "mk_pcg_set_tol", "mk_pcg_set_two_norm",
     "mk_pcg_set_rel_change", "mk_pcg_set_print_level", "mk_pcg_set_logging", "mk_pcg_set_precond",
-    "mk_pcg_set_check_every", "mk_pcg_setup", "mk_pcg_solve", "mk_pcg_get_num_iterations",
+    "mk_pcg_set_check_every", "mk_pcg_set_kernel_timing", "mk_pcg_get_kernel_timing", "mk_pcg_setup", "mk_pcg_solve", "mk_pcg_get_num_iterations",
     "mk_pcg_get_final_relative_residual_norm", "mk_pcg_get_converged",
     "mk_pcg_get_residual_history", "mk_pcg_destroy",
     "mk_bicgstab_create", "mk_bicgstab_set_max_iter", "mk_bicgstab_set_tol", "mk_bicgstab_set_print_level",
@@ -70,8 +70,8 @@ EXPORTS = [
     "mk_jacobi_create", "mk_jacobi_set_max_iter", "mk_jacobi_set_tol", "mk_jacobi_set_check_every",
     "mk_jacobi_setup", "mk_jacobi_solve", "mk_jacobi_get_num_iterations",
     "mk_jacobi_get_final_relative_residual_norm", "mk_jacobi_get_converged", "mk_jacobi_destroy",
-    "mk_partition_rows",
-    "mk_comm_get_unique_id", "mk_comm_create", "mk_comm_create_local", "mk_comm_self_test", "mk_comm_destroy",
+    "mk_partition_rows", "mk_halo_check_row_start", "mk_halo_ghost_columns", "mk_halo_plan_recv", "mk_halo_plan_send",
+    "mk_comm_get_unique_id", "mk_comm_create", "mk_comm_create_local", "mk_comm_self_test", "mk_comm_all_reduce_host", "mk_comm_destroy",
     "mk_dist_matrix_create", "mk_dist_matrix_destroy", "mk_dist_matrix_get_info", "mk_dist_matrix_get_diag_info", "mk_dist_matrix_set_spmv_kernel",
     "mk_dist_vector_create", "mk_dist_spmv", "mk_dist_pcg_solve", "mk_dist_jacobi_solve",
 ]
@@ -106,6 +106,7 @@ def load():
         "mk_dist_matrix_get_diag_info": [P, C.POINTER(MatrixInfo)],
         "mk_matrix_set_spmv_kernel": [P, C.c_int, C.c_int],
         "mk_matrix_generate_stencil": [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.POINTER(P)],
+        "mk_matrix_generate_stencil_scaled": [C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int64, C.c_int64, C.POINTER(P)],
         "mk_matrix_generate_banded": [C.c_int64, C.c_int, C.c_int64, C.c_int64, C.POINTER(P)],
         "mk_coo_generate_rmat": [C.c_int, C.c_uint64, C.c_uint64, C.c_double, C.c_double, C.c_double, C.POINTER(P)],
         "mk_coo_from_host": [C.POINTER(COO), C.POINTER(P)], "mk_coo_download": [P, C.POINTER(COO)],
@@ -119,6 +120,8 @@ def load():
         "mk_pcg_set_two_norm": [P, C.c_int], "mk_pcg_set_rel_change": [P, C.c_int],
         "mk_pcg_set_print_level": [P, C.c_int], "mk_pcg_set_logging": [P, C.c_int],
         "mk_pcg_set_precond": [P, C.c_int], "mk_pcg_set_check_every": [P, C.c_int],
+        "mk_pcg_set_kernel_timing": [P, C.c_int],
+        "mk_pcg_get_kernel_timing": [P, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.c_int],
         "mk_pcg_setup": [P, P, P, P], "mk_pcg_solve": [P, P, P, P],
         "mk_pcg_get_num_iterations": [P, C.POINTER(C.c_longlong)],
         "mk_pcg_get_final_relative_residual_norm": [P, C.POINTER(C.c_double)],
@@ -340,11 +343,15 @@ class Matrix:
         return cls(h)
 
     @classmethod
-    def stencil(cls, kind, nx, ny, nz=1, row_begin=0, row_end=None):
+    def stencil(cls, kind, nx, ny, nz=1, row_begin=0, row_end=None, scale_seed=None):
+        """scale_seed: D A D with a per-row scale in [1, 5) (variable coefficients), None: the plain stencil"""
         init()
         n = nx * ny * (1 if kind == 5 else nz)
         h = C.c_void_p()
-        _ck(load().mk_matrix_generate_stencil(kind, nx, ny, nz, row_begin, n if row_end is None else row_end, C.byref(h)))
+        if scale_seed is None:
+            _ck(load().mk_matrix_generate_stencil(kind, nx, ny, nz, row_begin, n if row_end is None else row_end, C.byref(h)))
+        else:
+            _ck(load().mk_matrix_generate_stencil_scaled(kind, nx, ny, nz, scale_seed, row_begin, n if row_end is None else row_end, C.byref(h)))
         return cls(h)
 
     @classmethod
@@ -419,6 +426,15 @@ class PCG:
         out = np.empty(capacity)
         n = _ck(load().mk_pcg_get_residual_history(self.h, out.ctypes.data, capacity))
         return out[:n]
+
+    def set_kernel_timing(self, on=True):
+        _ck(load().mk_pcg_set_kernel_timing(self.h, int(on)))
+
+    def kernel_timing(self):
+        """[(average ms, launches)] per kernel slot of a CG step, measured by HIP events inside the last solve"""
+        ns, ms, cnt = C.c_int(), (C.c_double * 3)(), (C.c_longlong * 3)()
+        _ck(load().mk_pcg_get_kernel_timing(self.h, C.byref(ns), ms, cnt, 3))
+        return [(ms[k], cnt[k]) for k in range(ns.value)]
 
     def __del__(self):
         if getattr(self, "h", None) and _lib is not None:

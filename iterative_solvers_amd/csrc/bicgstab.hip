@@ -19,7 +19,9 @@
 namespace mk {
 
 struct BicgState {
-  double res, alpha, gamma, r_norm, b_norm, eps;
+  // resv: <r0,r> ping-pong.  Iteration `it` reads resv[it & 1] (steps 1 and 3) and step 3 writes resv[(it + 1) & 1]:
+  // no kernel reads a field that a block of the same launch may already have rewritten.
+  double resv[2], alpha, gamma, r_norm, b_norm, eps;
   long long iter;
   int done;        // 0 running, 1 converged, 2 breakdown
   int converged;
@@ -87,7 +89,7 @@ static __global__ __launch_bounds__(kVecThreads) void bicg_init_scalars_kernel(c
     BicgState s;
     memset(&s, 0, sizeof(s));
     s.b_norm = sqrt(v[0]);
-    s.res = v[1];
+    s.resv[0] = v[1];
     s.r_norm = sqrt(v[1]);
     s.eps = tol * (s.b_norm > 0.0 ? s.b_norm : s.r_norm);
     s.done = (s.r_norm == 0.0) ? 1 : 0;   // hypre returns at once, zero iterations
@@ -100,12 +102,13 @@ static __global__ __launch_bounds__(kVecThreads) void bicg_init_scalars_kernel(c
 // alpha = res / <r0,q>;  x += alpha p;  r -= alpha q
 static __global__ __launch_bounds__(kVecThreads) void bicg_step1_kernel(int64_t n, const double *__restrict__ p, const double *__restrict__ q,
                                                                         double *__restrict__ x, double *__restrict__ r,
-                                                                        const double *__restrict__ slab_in, int nblocks_in, BicgState *st, int nt) {
-  if (st->done != 0) return;
+                                                                        const double *__restrict__ slab_in, int nblocks_in, BicgState *st, int nt,
+                                                                        int parity) {
+  if (block_flag_raised(&st->done)) return;
   __shared__ double smem[kVecThreads / 64];
   double d[1];
   reduce_slab<1, kVecThreads>(slab_in, nblocks_in, kSlabStride, d, smem);
-  const double temp = d[0], res = st->res;
+  const double temp = d[0], res = st->resv[parity];
   const bool leader = (blockIdx.x == 0 && threadIdx.x == 0);
   if (!(fabs(temp) >= kEpsMac)) {
     if (leader) { st->iter += 1; st->breakdown = 1; st->done = 2; }
@@ -177,7 +180,10 @@ static __global__ __launch_bounds__(kVecThreads) void bicg_step2_kernel(int64_t 
 
 // ||r|| of the recursive residual; decides whether the true residual has to be formed
 static __global__ __launch_bounds__(kVecThreads) void bicg_norm_kernel(const double *slab, int nblocks, BicgState *st, double *norms) {
-  if (st->done != 0) return;
+  if (st->done != 0) {   // one block: after a stop the true-residual kernels of the iterations still queued return at once
+    if (threadIdx.x == 0) st->skip_true = 1;
+    return;
+  }
   __shared__ double smem[kVecThreads / 64];
   double v[1];
   reduce_slab<1, kVecThreads>(slab, nblocks, kSlabStride, v, smem);
@@ -198,20 +204,20 @@ static __global__ void copy_unless_kernel(double *__restrict__ dst, const double
 // Convergence on the true residual; beta = (<r0,r>/res)(alpha/gamma); p = beta (p - gamma q) + r
 static __global__ __launch_bounds__(kVecThreads) void bicg_step3_kernel(int64_t n, const double *__restrict__ r, const double *__restrict__ q,
                                                                         double *__restrict__ p, const double *__restrict__ slab_in,
-                                                                        int nblocks_in, BicgState *st, int nt) {
-  if (st->done != 0) return;
+                                                                        int nblocks_in, BicgState *st, int nt, int parity) {
+  if (block_flag_raised(&st->done)) return;
   __shared__ double smem[2 * (kVecThreads / 64)];
   double d[2];
   reduce_slab<2, kVecThreads>(slab_in, nblocks_in, kSlabStride, d, smem);
   const bool leader = (blockIdx.x == 0 && threadIdx.x == 0);
+  // skip_true, alpha, gamma and resv[parity] were written by earlier launches and are not written here
   const bool cand = (st->skip_true == 0);
-  const double res_old = st->res, alpha = st->alpha, gamma = st->gamma, eps = st->eps;
-  __syncthreads();   // all threads hold the state before the leader rewrites it
+  const double res_old = st->resv[parity], alpha = st->alpha, gamma = st->gamma, eps = st->eps;
   if (cand) {
     const double rn = sqrt(d[1]);
     if (leader) st->r_norm = rn;
     if (rn <= eps) {
-      if (leader) { st->converged = 1; st->done = 1; st->skip_true = 1; }
+      if (leader) { st->converged = 1; st->done = 1; }
       return;
     }
   }
@@ -224,7 +230,7 @@ static __global__ __launch_bounds__(kVecThreads) void bicg_step3_kernel(int64_t 
   beta *= res;
   beta *= alpha;
   if (!(fabs(gamma) >= kEpsMac)) {
-    if (leader) { st->res = res; st->breakdown = 3; st->done = 2; }
+    if (leader) { st->resv[parity ^ 1] = res; st->breakdown = 3; st->done = 2; }
     return;
   }
   beta /= gamma;
@@ -246,7 +252,7 @@ static __global__ __launch_bounds__(kVecThreads) void bicg_step3_kernel(int64_t 
     t = beta * t;
     p[n - 1] = t + r[n - 1];
   }
-  if (leader) st->res = res;
+  if (leader) st->resv[parity ^ 1] = res;
 }
 
 }  // namespace mk
@@ -349,7 +355,7 @@ int mk_bicgstab_solve(mk_bicgstab *S, const mk_matrix *A, const mk_vector *b, mk
     int *done = &S->state->done, *skip = &S->state->skip_true;
     MK_TRY(launch_spmv(A, 1.0, S->p, 0.0, S->q, done));
     hipLaunchKernelGGL(dot2_kernel, grid, block, 0, c.stream, n, S->r0, S->q, nullptr, nullptr, S->slab1, done, nt);
-    hipLaunchKernelGGL(bicg_step1_kernel, grid, block, 0, c.stream, n, S->p, S->q, x->d, S->r, S->slab1, vb, S->state, nt);
+    hipLaunchKernelGGL(bicg_step1_kernel, grid, block, 0, c.stream, n, S->p, S->q, x->d, S->r, S->slab1, vb, S->state, nt, it & 1);
     MK_TRY(launch_spmv(A, 1.0, S->r, 0.0, S->s, done));
     hipLaunchKernelGGL(dot2_kernel, grid, block, 0, c.stream, n, S->r, S->s, S->s, S->s, S->slab2, done, nt);
     hipLaunchKernelGGL(bicg_step2_kernel, grid, block, 0, c.stream, n, S->s, S->r0, x->d, S->r, S->slab2, vb, S->slab3, S->state, nt);
@@ -358,7 +364,7 @@ int mk_bicgstab_solve(mk_bicgstab *S, const mk_matrix *A, const mk_vector *b, mk
     hipLaunchKernelGGL(copy_unless_kernel, grid, dim3(256), 0, c.stream, S->r, b->d, n, skip);
     MK_TRY(launch_spmv(A, -1.0, x->d, 1.0, S->r, skip));
     hipLaunchKernelGGL(dot2_kernel, grid, block, 0, c.stream, n, S->r0, S->r, S->r, S->r, S->slab3, skip, nt);   // only behind a true residual
-    hipLaunchKernelGGL(bicg_step3_kernel, grid, block, 0, c.stream, n, S->r, S->q, S->p, S->slab3, vb, S->state, nt);
+    hipLaunchKernelGGL(bicg_step3_kernel, grid, block, 0, c.stream, n, S->r, S->q, S->p, S->slab3, vb, S->state, nt, it & 1);
     if ((it + 1) % S->check_every == 0) {
       MK_HIP(hipMemcpyAsync(&hst[0], S->state, sizeof(BicgState), hipMemcpyDeviceToHost, c.stream));
       MK_HIP(hipStreamSynchronize(c.stream));
@@ -527,7 +533,10 @@ static __global__ __launch_bounds__(kVecThreads) void cgnr_step1_kernel(int64_t 
 // slab_rr: <r,r> of the recursive residual; slab_tt: <t,t>.  Logs the norm, raises the candidate flag
 static __global__ __launch_bounds__(kVecThreads) void cgnr_norm_kernel(const double *slab_rr, const double *slab_tt, int nblocks, CgnrState *st,
                                                                        double *norms) {
-  if (st->done != 0) return;
+  if (st->done != 0) {   // one block: see bicg_norm_kernel
+    if (threadIdx.x == 0) st->skip_true = 1;
+    return;
+  }
   __shared__ double smem[kVecThreads / 64];
   double v[1], g[1];
   reduce_slab<1, kVecThreads>(slab_rr, nblocks, kSlabStride, v, smem);
@@ -544,7 +553,7 @@ static __global__ __launch_bounds__(kVecThreads) void cgnr_norm_kernel(const dou
 // slab_in: <r,r> of r as it stands now (b - A x if it was a candidate).  beta = gamma/gamma_old; p = beta p + t
 static __global__ __launch_bounds__(kVecThreads) void cgnr_step2_kernel(int64_t n, const double *__restrict__ t, double *__restrict__ p,
                                                                         const double *__restrict__ slab_in, int nblocks_in, CgnrState *st, int nt) {
-  if (st->done != 0) return;
+  if (block_flag_raised(&st->done)) return;
   __shared__ double smem[kVecThreads / 64];
   const bool leader = (blockIdx.x == 0 && threadIdx.x == 0);
   const bool cand = (st->skip_true == 0);
@@ -554,7 +563,7 @@ static __global__ __launch_bounds__(kVecThreads) void cgnr_step2_kernel(int64_t 
     reduce_slab<1, kVecThreads>(slab_in, nblocks_in, kSlabStride, d, smem);
     if (leader) st->i_prod = d[0];
     if (d[0] < eps) {
-      if (leader) { st->converged = 1; st->done = 1; st->skip_true = 1; }
+      if (leader) { st->converged = 1; st->done = 1; }   // skip_true is read at entry by every block: not written here
       return;
     }
   }

@@ -1,6 +1,8 @@
 // context.hip -- library life cycle, error text, vectors, timers, host-side partitioner.
 #include "mk_internal.h"
 
+#include <algorithm>
+
 namespace mk {
 
 static thread_local char g_err[1024] = "no error";
@@ -207,6 +209,70 @@ int mk_partition_rows(int64_t nrows, const int64_t *rowptr, int nparts, int64_t 
     cursor += step;
   }
   row_start[nparts] = nrows;
+  return MK_OK;
+}
+
+// ------------------------------------------------------------- exchange planning (host only)
+// The host half of what HYPRE's ParCSR communication package holds (behind HYPRE_IJMatrixAssemble, solvers.c:362):
+// which x entries a rank needs from which owner, and what it has to send.  mk_dist_matrix_create runs exactly these
+// functions (dist.hip split_block / build_plan_*); they need no GPU, so the multi-process CPU test drives them too.
+
+int mk_halo_check_row_start(int nranks, const int64_t *row_start, int64_t n_global) {
+  if (!row_start || nranks < 1) return fail(MK_ERR_INVALID, "row_start: null or no ranks");
+  if (n_global > 0x7fffffffLL) return fail(MK_ERR_UNSUPPORTED, "more than 2^31-1 global columns");
+  if (row_start[0] != 0 || row_start[nranks] != n_global) return fail(MK_ERR_INVALID, "row_start must run from 0 to n_global");
+  for (int q = 0; q < nranks; q++)
+    if (row_start[q + 1] < row_start[q]) return fail(MK_ERR_INVALID, "row_start decreases");
+  return MK_OK;
+}
+
+// ghosts = sorted, distinct global column ids outside [row_begin, row_end) that the block refers to
+int mk_halo_ghost_columns(int64_t nrows, const int *rowptr, const int *col, int64_t row_begin, int64_t row_end, int64_t n_global,
+                          int *ghosts, int64_t capacity, int64_t *n_ghost) {
+  if (!rowptr || !n_ghost || nrows < 0 || (rowptr[nrows] > 0 && !col)) return fail(MK_ERR_INVALID, "mk_halo_ghost_columns: bad argument");
+  std::vector<int> g;
+  for (int64_t k = 0; k < rowptr[nrows]; k++) {
+    const int c = col[k];
+    if (c < 0 || c >= n_global) return fail(MK_ERR_INVALID, "mk_halo_ghost_columns: column %d outside [0,%lld)", c, (long long)n_global);
+    if (c < row_begin || c >= row_end) g.push_back(c);
+  }
+  std::sort(g.begin(), g.end());
+  g.erase(std::unique(g.begin(), g.end()), g.end());
+  *n_ghost = (int64_t)g.size();
+  if (ghosts) {
+    if ((int64_t)g.size() > capacity) return fail(MK_ERR_INVALID, "mk_halo_ghost_columns: %zu ghosts, room for %lld", g.size(), (long long)capacity);
+    std::copy(g.begin(), g.end(), ghosts);
+  }
+  return MK_OK;
+}
+
+// owners are contiguous row blocks and the ghosts are sorted: the ghosts of owner q are one contiguous run
+int mk_halo_plan_recv(int nranks, int rank, const int64_t *row_start, const int *ghosts, int64_t n_ghost, int *recv_cnt, int *recv_off) {
+  if (!row_start || !recv_cnt || !recv_off || nranks < 1 || rank < 0 || rank >= nranks || n_ghost < 0 || (n_ghost && !ghosts))
+    return fail(MK_ERR_INVALID, "mk_halo_plan_recv: bad argument");
+  recv_off[0] = 0;
+  for (int q = 0; q < nranks; q++) {
+    const int lo_v = (int)std::min<int64_t>(row_start[q], 0x7fffffff), hi_v = (int)std::min<int64_t>(row_start[q + 1], 0x7fffffff);
+    const int *lo = std::lower_bound(ghosts, ghosts + n_ghost, lo_v);
+    const int *hi = std::lower_bound(ghosts, ghosts + n_ghost, hi_v);
+    recv_cnt[q] = (int)(hi - lo);
+    recv_off[q + 1] = recv_off[q] + recv_cnt[q];
+  }
+  if (recv_cnt[rank] != 0) return fail(MK_ERR_INVALID, "exchange plan: own rows listed as ghosts");
+  if (recv_off[nranks] != n_ghost) return fail(MK_ERR_INVALID, "exchange plan: %lld ghosts, %d of them inside the row ranges", (long long)n_ghost, recv_off[nranks]);
+  return MK_OK;
+}
+
+// recv_cnt_all[q * nranks + r] = what rank q receives from rank r (the all-gathered recv_cnt rows)
+int mk_halo_plan_send(int nranks, int rank, const int *recv_cnt_all, int *send_cnt, int *send_off) {
+  if (!recv_cnt_all || !send_cnt || !send_off || nranks < 1 || rank < 0 || rank >= nranks) return fail(MK_ERR_INVALID, "mk_halo_plan_send: bad argument");
+  send_off[0] = 0;
+  for (int q = 0; q < nranks; q++) {
+    send_cnt[q] = recv_cnt_all[(size_t)q * nranks + rank];
+    if (send_cnt[q] < 0) return fail(MK_ERR_INVALID, "exchange plan: negative count from rank %d", q);
+    send_off[q + 1] = send_off[q] + send_cnt[q];
+  }
+  if (send_cnt[rank] != 0) return fail(MK_ERR_INVALID, "exchange plan: a rank sends to itself");
   return MK_OK;
 }
 

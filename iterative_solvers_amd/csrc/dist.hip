@@ -330,16 +330,10 @@ static int split_block(mk_matrix *A, mk_dist_matrix *D) {
   MK_HIP(hipStreamSynchronize(c.stream));
   MK_HIP(hipGetLastError());
   dev_free(flags); dev_free(cnt_d); dev_free(cnt_o); dev_free(has_o); dev_free(d_tot);
-  // receive plan: ghosts are sorted by global id, owners are contiguous row blocks
+  // receive plan: ghosts are sorted by global id, owners are contiguous row blocks (host logic shared with the CPU tests)
   D->recv_cnt.assign(D->nranks, 0);
   D->recv_off.assign(D->nranks + 1, 0);
-  for (int q = 0; q < D->nranks; q++) {
-    auto lo = std::lower_bound(D->h_ghost.begin(), D->h_ghost.end(), (int)D->row_start[q]);
-    auto hi = std::lower_bound(D->h_ghost.begin(), D->h_ghost.end(), (int)std::min<int64_t>(D->row_start[q + 1], 0x7fffffff));
-    D->recv_cnt[q] = (int)(hi - lo);
-    D->recv_off[q + 1] = D->recv_off[q] + D->recv_cnt[q];
-  }
-  if (D->recv_cnt[D->rank] != 0) return fail(MK_ERR_INVALID, "dist split: own rows listed as ghosts");
+  MK_TRY(mk_halo_plan_recv(D->nranks, D->rank, D->row_start.data(), D->h_ghost.data(), D->n_ghost, D->recv_cnt.data(), D->recv_off.data()));
   const double mean_o = D->n_offd_rows ? (double)D->offd.nnz / D->n_offd_rows : 0.0;
   // lanes per row: up to 8 entries per lane (a 27-point slab face has 9 per row: 2 lanes; 16 lanes left most of the
   // chip idle on the 0.5 M short rows: 37 us against 12 us)
@@ -349,9 +343,11 @@ static int split_block(mk_matrix *A, mk_dist_matrix *D) {
   return MK_OK;
 }
 
-static int finish_send_plan(mk_dist_matrix *D) {
+// recv_all[q * nranks + r] = what rank q receives from rank r
+static int finish_send_plan(mk_dist_matrix *D, const std::vector<int> &recv_all) {
+  D->send_cnt.assign(D->nranks, 0);
   D->send_off.assign(D->nranks + 1, 0);
-  for (int q = 0; q < D->nranks; q++) D->send_off[q + 1] = D->send_off[q] + D->send_cnt[q];
+  MK_TRY(mk_halo_plan_send(D->nranks, D->rank, recv_all.data(), D->send_cnt.data(), D->send_off.data()));
   D->n_send = D->send_off[D->nranks];
   MK_TRY(dev_alloc(&D->send_idx, (size_t)D->n_send));
   MK_TRY(dev_alloc(&D->sendbuf, (size_t)D->n_send));
@@ -372,9 +368,7 @@ static int build_plan_rccl(mk_dist_matrix *D) {
   MK_HIP(hipMemcpyAsync(all.data(), d_all, sizeof(int) * P * P, hipMemcpyDeviceToHost, c.stream));
   MK_HIP(hipStreamSynchronize(c.stream));
   dev_free(d_cnt); dev_free(d_all);
-  D->send_cnt.assign(P, 0);
-  for (int q = 0; q < P; q++) D->send_cnt[q] = all[(size_t)q * P + D->rank];   // what q needs from me
-  MK_TRY(finish_send_plan(D));
+  MK_TRY(finish_send_plan(D, all));   // what every q needs from me
   MK_NCCL(g_rccl.GroupStart());
   for (int q = 0; q < P; q++) {
     if (D->recv_cnt[q]) MK_NCCL(g_rccl.Send(D->ghost_global + D->recv_off[q], (size_t)D->recv_cnt[q], ncclInt32, q, cm->p2p, c.stream));
@@ -390,11 +384,11 @@ static int build_plan_rccl(mk_dist_matrix *D) {
 static int build_plan_local(LocalWorld *W) {
   Context &c = ctx();
   const int P = W->nranks;
+  std::vector<int> all((size_t)P * P);   // the table an all-gather of recv_cnt gives over RCCL
+  for (int q = 0; q < P; q++) std::copy(W->mats[q]->recv_cnt.begin(), W->mats[q]->recv_cnt.end(), all.begin() + (size_t)q * P);
   for (int r = 0; r < P; r++) {
     mk_dist_matrix *D = W->mats[r];
-    D->send_cnt.assign(P, 0);
-    for (int q = 0; q < P; q++) D->send_cnt[q] = W->mats[q]->recv_cnt[r];
-    MK_TRY(finish_send_plan(D));
+    MK_TRY(finish_send_plan(D, all));
     for (int q = 0; q < P; q++)
       if (D->send_cnt[q])
         MK_HIP(hipMemcpyAsync(D->send_idx + D->send_off[q], W->mats[q]->ghost_global + W->mats[q]->recv_off[r],
@@ -466,12 +460,15 @@ static int all_reduce(int R, mk_dist_matrix **A, double **bufs, int count) {
   return MK_OK;
 }
 
+// max_blocks: room left in the slab the partials go to (they sit behind the diag kernel's partials)
 template <bool DOT, bool SET = false>
-static int launch_offd(const mk_dist_matrix *D, const double *xext, double *y, double alpha, double *slab, const int *done, int *nblocks) {
+static int launch_offd(const mk_dist_matrix *D, const double *xext, double *y, double alpha, double *slab, const int *done, int *nblocks,
+                       int max_blocks = 1024) {
   Context &c = ctx();
   const int G = D->offd_lanes;
   const int rows_per_block = 256 / G;
-  int blocks = std::max(1, std::min((D->n_offd_rows + rows_per_block - 1) / rows_per_block, 1024));
+  if (max_blocks < 1) return fail(MK_ERR_UNSUPPORTED, "row-block CG: the diag block's %d reduction partials leave no room for the off-rank product's", kSlabStride - max_blocks);
+  int blocks = std::max(1, std::min((D->n_offd_rows + rows_per_block - 1) / rows_per_block, std::min(1024, max_blocks)));
   if (nblocks) *nblocks = blocks;
   if (D->n_offd_rows == 0 && !DOT) return MK_OK;
 #define MK_OFFD(GG) case GG: hipLaunchKernelGGL((offd_spmv_kernel<GG, DOT, SET>), dim3(blocks), dim3(256), 0, c.stream, D->n_offd_rows, \
@@ -483,11 +480,13 @@ static int launch_offd(const mk_dist_matrix *D, const double *xext, double *y, d
 }
 
 // t[i] = (offd x_ghost)[i] over the rows that touch ghosts, partial of <t, x_local> (fused row-block CG step)
-static int launch_offd_compact(const mk_dist_matrix *D, const double *xext, double *t, double *slab, const int *done, int *nblocks) {
+static int launch_offd_compact(const mk_dist_matrix *D, const double *xext, double *t, double *slab, const int *done, int *nblocks,
+                               int max_blocks) {
   Context &c = ctx();
   const int G = D->offd_lanes;
   const int rows_per_block = 256 / G;
-  int blocks = std::max(1, std::min((D->n_offd_rows + rows_per_block - 1) / rows_per_block, 1024));
+  if (max_blocks < 1) return fail(MK_ERR_UNSUPPORTED, "row-block CG: the diag block's %d reduction partials leave no room for the off-rank product's", kSlabStride - max_blocks);
+  int blocks = std::max(1, std::min((D->n_offd_rows + rows_per_block - 1) / rows_per_block, std::min(1024, max_blocks)));
   if (nblocks) *nblocks = blocks;
 #define MK_OFFD(GG) case GG: hipLaunchKernelGGL((offd_spmv_kernel<GG, true, true, true>), dim3(blocks), dim3(256), 0, c.stream, D->n_offd_rows, \
     D->offd.rowptr, D->offd.col, D->offd.val, D->offd_rows, xext + D->n_local, xext, t, 1.0, slab, done); break;
@@ -614,6 +613,24 @@ int mk_comm_self_test(mk_comm *cm) {
   return MK_OK;
 }
 
+int mk_comm_all_reduce_host(mk_comm *cm, double *values, int count, int op) {
+  MK_REQUIRE_INIT();
+  if (!values || count < 1 || count > 64 || (op != 0 && op != 1)) return fail(MK_ERR_INVALID, "mk_comm_all_reduce_host: bad argument");
+  if (!cm || cm->local || cm->nranks == 1) return MK_OK;
+  Context &c = ctx();
+  double *d = nullptr;
+  MK_TRY(dev_alloc(&d, (size_t)count));
+  hipError_t e = hipMemcpyAsync(d, values, sizeof(double) * count, hipMemcpyHostToDevice, c.stream);
+  ncclResult_t r = ncclSuccess;
+  if (e == hipSuccess) r = g_rccl.AllReduce(d, d, (size_t)count, ncclDouble, op == 1 ? ncclMax : ncclSum, cm->coll, c.stream);
+  if (e == hipSuccess && r == ncclSuccess) e = hipMemcpyAsync(values, d, sizeof(double) * count, hipMemcpyDeviceToHost, c.stream);
+  const hipError_t e2 = hipStreamSynchronize(c.stream);
+  dev_free(d);
+  if (r != ncclSuccess) return fail(MK_ERR_COMM, "mk_comm_all_reduce_host: %s", g_rccl.GetErrorString(r));
+  if (e != hipSuccess || e2 != hipSuccess) return fail(MK_ERR_HIP, "mk_comm_all_reduce_host: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+  return MK_OK;
+}
+
 int mk_comm_destroy(mk_comm *cm) {
   if (!cm) return MK_OK;
   if (ctx().ready) (void)hipDeviceSynchronize();
@@ -640,10 +657,7 @@ int mk_dist_matrix_create(mk_matrix *A, int64_t n_global, const int64_t *row_sta
   if (!A || !row_start || !out) return fail(MK_ERR_INVALID, "mk_dist_matrix_create: null argument");
   const int P = comm ? comm->nranks : 1, me = comm ? comm->rank : 0;
   if (comm && !comm->local && !comm->coll) return fail(MK_ERR_INVALID, "mk_dist_matrix_create: communicator not initialised");
-  if (n_global > 0x7fffffffLL) return fail(MK_ERR_UNSUPPORTED, "mk_dist_matrix_create: more than 2^31-1 global columns");
-  if (row_start[0] != 0 || row_start[P] != n_global) return fail(MK_ERR_INVALID, "mk_dist_matrix_create: row_start must run from 0 to n_global");
-  for (int q = 0; q < P; q++)
-    if (row_start[q + 1] < row_start[q]) return fail(MK_ERR_INVALID, "mk_dist_matrix_create: row_start decreases");
+  MK_TRY(mk_halo_check_row_start(P, row_start, n_global));
   if (A->nrows != row_start[me + 1] - row_start[me] || A->ncols != n_global)
     return fail(MK_ERR_INVALID, "mk_dist_matrix_create: block is %lld x %lld, expected %lld x %lld", (long long)A->nrows,
                 (long long)A->ncols, (long long)(row_start[me + 1] - row_start[me]), (long long)n_global);
@@ -657,8 +671,7 @@ int mk_dist_matrix_create(mk_matrix *A, int64_t n_global, const int64_t *row_sta
   if (rc == MK_OK) {
     if (comm == nullptr) {
       if (P != 1) rc = fail(MK_ERR_INVALID, "mk_dist_matrix_create: more than one rank needs a communicator");
-      D->send_cnt.assign(1, 0);
-      if (rc == MK_OK) rc = finish_send_plan(D);
+      if (rc == MK_OK) rc = finish_send_plan(D, std::vector<int>(1, 0));
       D->plan_ready = true;
     } else if (comm->local) {
       LocalWorld *W = comm->world;
@@ -831,7 +844,13 @@ int mk_dist_pcg_solve(int R, mk_pcg **solvers, mk_dist_matrix **A, mk_vector **b
     hipLaunchKernelGGL(pcg_init_scalars_kernel, dim3(1), dim3(kVecThreads), 0, c.stream, W[r].buf, 1, 1, S0->tol, two_norm, W[r].state, W[r].norms);
   MK_DH(hipMemcpyAsync(&hst[0], W[0].state, sizeof(PcgState), hipMemcpyDeviceToHost, c.stream));
   MK_DH(hipStreamSynchronize(c.stream));
-  const bool zero_rhs = !(hst[0].bi_prod > 0.0);
+  if (!std::isfinite(hst[0].bi_prod) || hst[0].bi_prod < 0.0 || !std::isfinite(hst[0].i_prod)) {
+    // hypre_PCGSolve's ieee_check: NaN or Inf in b, x0 or A is an error, not a zero right-hand side
+    for (int r = 0; r < R; r++) solvers[r]->breakdown = 4;
+    cleanup();
+    return fail(MK_ERR_INVALID, "mk_dist_pcg_solve: <b,b> = %g, <r,r> = %g: NaN or Inf in the right-hand side, initial guess or matrix", hst[0].bi_prod, hst[0].i_prod);
+  }
+  const bool zero_rhs = (hst[0].bi_prod == 0.0);
   if (zero_rhs) {
     for (int r = 0; r < R; r++)
       if (A[r]->n_local) hipLaunchKernelGGL(copy_kernel, dim3(vb[r]), dim3(256), 0, c.stream, x[r]->d, b[r]->d, A[r]->n_local);
@@ -860,8 +879,10 @@ int mk_dist_pcg_solve(int R, mk_pcg **solvers, mk_dist_matrix **A, mk_vector **b
     }
     for (int r = 0; r < R; r++) {                                                 // K1b: offd block once the ghosts are in
       MK_D(halo_wait(A[r], rccl));
-      if (fusedv[r]) MK_D(launch_offd_compact(A[r], pv[r], W[r].t, W[r].slab1 + nb1[r], &W[r].state->done, &nb2[r]));
-      else MK_D(launch_offd<true>(A[r], pv[r], W[r].s, 1.0, W[r].slab1 + nb1[r], &W[r].state->done, &nb2[r]));
+      // the off-rank partials sit behind the diag kernel's in the same slab: nb1 + nb2 <= kSlabStride, or component 0
+      // of the off-rank part would run into component 1 of the diag part
+      if (fusedv[r]) MK_D(launch_offd_compact(A[r], pv[r], W[r].t, W[r].slab1 + nb1[r], &W[r].state->done, &nb2[r], kSlabStride - nb1[r]));
+      else MK_D(launch_offd<true>(A[r], pv[r], W[r].s, 1.0, W[r].slab1 + nb1[r], &W[r].state->done, &nb2[r], kSlabStride - nb1[r]));
       hipLaunchKernelGGL((finalize_slab_kernel<2>), dim3(1), dim3(kVecThreads), 0, c.stream, W[r].slab1, nb1[r] + nb2[r], W[r].buf);
     }
     MK_D(all_reduce(R, A, bufs.data(), 2));                                       // <s,p>, <p,p>
@@ -979,7 +1000,11 @@ int mk_dist_jacobi_solve(int R, mk_jacobi **solvers, mk_dist_matrix **A, mk_vect
   for (int r = 0; r < R; r++) hipLaunchKernelGGL(jacobi_init_kernel, dim3(1), dim3(256), 0, c.stream, W[r].buf, 1, 1, S0->tol, W[r].state);
   MK_DH(hipMemcpyAsync(hst, W[0].state, sizeof(JacobiState), hipMemcpyDeviceToHost, c.stream));
   MK_DH(hipStreamSynchronize(c.stream));
-  if (!(hst->bb > 0.0)) {
+  if (!std::isfinite(hst->bb) || hst->bb < 0.0) {
+    cleanup();
+    return fail(MK_ERR_INVALID, "mk_dist_jacobi_solve: <b,b> = %g: NaN or Inf in the right-hand side", hst->bb);
+  }
+  if (hst->bb == 0.0) {
     for (int r = 0; r < R; r++)
       if (A[r]->n_local) hipLaunchKernelGGL(copy_kernel, dim3(vb[r]), dim3(256), 0, c.stream, x[r]->d, b[r]->d, A[r]->n_local);
     cleanup();

@@ -32,6 +32,24 @@ __global__ void stencil_count_kernel(StencilGeom g, int64_t row_begin, int64_t n
   }
 }
 
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x);
+
+// Row scale of the variable-coefficient operators: s_i = (1024 + 12 hash bits) / 1024 in [1, 5), a dyadic rational
+// of 13 bits, so that (a_ij * s_i) * s_j is exact in fp64 (no rounding, no dependence on contraction) and symmetric.
+// D A D with D = diag(s) > 0 keeps A symmetric positive definite.  oracle/oracle.c orc_row_scale is the same.
+__device__ __forceinline__ double row_scale(uint64_t seed, int64_t row) {
+  const uint64_t h = splitmix64(seed ^ ((uint64_t)row * 0xD1B54A32D192ED03ULL));
+  return (double)(1024 + (int)(h >> 52)) * (1.0 / 1024.0);
+}
+
+__global__ void scale_sym_kernel(int64_t nlocal, int64_t row_begin, uint64_t seed, const int *__restrict__ rowptr,
+                                 const int *__restrict__ col, double *__restrict__ val) {
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < nlocal; r += (int64_t)gridDim.x * blockDim.x) {
+    const double si = row_scale(seed, row_begin + r);
+    for (int k = rowptr[r]; k < rowptr[r + 1]; k++) val[k] = (val[k] * si) * row_scale(seed, col[k]);
+  }
+}
+
 __global__ void stencil_fill_kernel(StencilGeom g, int64_t row_begin, int64_t nlocal, const int *__restrict__ rowptr,
                                     int *__restrict__ col, double *__restrict__ val) {
   for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < nlocal; r += (int64_t)gridDim.x * blockDim.x) {
@@ -165,6 +183,18 @@ int mk_matrix_generate_stencil(int kind, int nx, int ny, int nz, int64_t row_beg
   }
   dev_free(counts);
   if (rc != MK_OK) { mk_matrix_destroy(M); return rc; }
+  *A = M;
+  return MK_OK;
+}
+
+int mk_matrix_generate_stencil_scaled(int kind, int nx, int ny, int nz, uint64_t seed, int64_t row_begin, int64_t row_end, mk_matrix **A) {
+  mk_matrix *M = nullptr;
+  MK_TRY(mk_matrix_generate_stencil(kind, nx, ny, nz, row_begin, row_end, &M));
+  if (M->nrows > 0) {
+    hipLaunchKernelGGL(scale_sym_kernel, dim3(grid_for(M->nrows)), dim3(256), 0, ctx().stream, M->nrows, row_begin, seed, M->rowptr, M->col, M->val);
+    hipError_t e = hipStreamSynchronize(ctx().stream);
+    if (e != hipSuccess) { mk_matrix_destroy(M); return fail(MK_ERR_HIP, "stencil scaling: %s", hipGetErrorString(e)); }
+  }
   *A = M;
   return MK_OK;
 }

@@ -30,6 +30,8 @@ static void pcg_release(mk_pcg *S) {
   S->state = nullptr;
   for (int k = 0; k < 2; k++)
     if (S->ev[k]) { (void)hipEventDestroy(S->ev[k]); S->ev[k] = nullptr; }
+  for (hipEvent_t e : S->tev) (void)hipEventDestroy(e);
+  S->tev.clear();
   S->n = 0;
 }
 
@@ -61,6 +63,7 @@ MK_PCG_SETTER(mk_pcg_set_print_level, print_level, int, v >= 0)
 MK_PCG_SETTER(mk_pcg_set_logging, logging, int, v >= 0)
 MK_PCG_SETTER(mk_pcg_set_precond, precond, int, v == MK_PRECOND_NONE || v == MK_PRECOND_JACOBI)
 MK_PCG_SETTER(mk_pcg_set_check_every, check_every, int, v >= 1)
+MK_PCG_SETTER(mk_pcg_set_kernel_timing, timing, int, v == 0 || v == 1)
 #undef MK_PCG_SETTER
 
 int mk_pcg_setup(mk_pcg *S, const mk_matrix *A, const mk_vector *b, const mk_vector *x) {
@@ -109,7 +112,12 @@ int mk_pcg_solve(mk_pcg *S, const mk_matrix *A, const mk_vector *b, mk_vector *x
   hipLaunchKernelGGL(pcg_init_scalars_kernel, dim3(1), dim3(kVecThreads), 0, c.stream, S->slab2, vb, kSlabStride, S->tol, S->two_norm, S->state, S->norms);
   MK_HIP(hipMemcpyAsync(&hst[0], S->state, sizeof(PcgState), hipMemcpyDeviceToHost, c.stream));
   MK_HIP(hipStreamSynchronize(c.stream));
-  if (!(hst[0].bi_prod > 0.0)) {
+  if (!std::isfinite(hst[0].bi_prod) || hst[0].bi_prod < 0.0 || !std::isfinite(hst[0].i_prod)) {
+    // hypre_PCGSolve's ieee_check: NaN or Inf in b, x0 or A is an error, not a zero right-hand side
+    S->breakdown = 4;
+    return fail(MK_ERR_INVALID, "mk_pcg_solve: <b,b> = %g, <r,r> = %g: NaN or Inf in the right-hand side, initial guess or matrix", hst[0].bi_prod, hst[0].i_prod);
+  }
+  if (hst[0].bi_prod == 0.0) {
     // hypre_PCGSolve: zero right-hand side -> x = b, zero iterations, norm 0
     hipLaunchKernelGGL(copy_kernel, dim3(vb), dim3(256), 0, c.stream, x->d, b->d, n);
     MK_HIP(hipStreamSynchronize(c.stream));
@@ -135,8 +143,20 @@ int mk_pcg_solve(mk_pcg *S, const mk_matrix *A, const mk_vector *b, mk_vector *x
   static const int no_pfuse = getenv("MK_NO_FUSED_K3") ? atoi(getenv("MK_NO_FUSED_K3")) : 0;
   const bool fuse_p = fused && !no_pfuse && (!dinv || sweep_uniform_diag(A, &zscale));
   int nb2 = 0;
+  // kernel timing: an event in front of every kernel of iterations 1 .. kTimedIters (the first iteration runs another
+  // first kernel on the fused path) and one behind the last of them
+  const int nslots = fused ? (fuse_p ? 2 : 3) : 3;
+  const int timed_iters = S->timing ? std::min(mk_pcg::kTimedIters, S->max_iter - 1) : 0;
+  if (timed_iters > 0 && S->tev.empty()) {
+    S->tev.resize((size_t)mk_pcg::kTimedIters * mk_pcg::kTimedSlots + 1, nullptr);
+    for (auto &e : S->tev) MK_HIP(hipEventCreate(&e));
+  }
+  int tev_used = 0;
+  auto stamp = [&](int it) { if (it >= 1 && it <= timed_iters) (void)hipEventRecord(S->tev[tev_used++], c.stream); };
   for (int it = 0; it < S->max_iter && !stop; it++) {
     int nb1 = 0;
+    if (it == timed_iters + 1 && tev_used > 0 && tev_used == timed_iters * nslots) (void)hipEventRecord(S->tev[tev_used++], c.stream);
+    stamp(it);
     if (fused) {
       if (fuse_p && it > 0) {
         MK_TRY(launch_sweep_cg_pdots(A, S->r, pcur, palt, zscale, S->slab2, nb2, kSlabStride, S->slab1, S->state, S->two_norm,
@@ -145,8 +165,10 @@ int mk_pcg_solve(mk_pcg *S, const mk_matrix *A, const mk_vector *b, mk_vector *x
       } else {
         MK_TRY(launch_sweep_cg_dots(A, pcur, S->slab1, S->state, &nb1));
       }
+      stamp(it);
       MK_TRY(launch_sweep_cg_resid_x(A, pcur, S->r, x->d, dinv, S->slab1, nb1, kSlabStride, S->slab2, S->state, &nb2));
       if (!fuse_p) {
+        stamp(it);
         if (dinv)
           hipLaunchKernelGGL((pcg_update_p_kernel<true>), dim3(vb), dim3(kVecThreads), 0, c.stream, n, S->r, dinv, pcur, S->slab2, nb2, kSlabStride, S->two_norm, S->rel_change, S->state, S->norms, (int)nt_rows(n));
         else
@@ -154,11 +176,14 @@ int mk_pcg_solve(mk_pcg *S, const mk_matrix *A, const mk_vector *b, mk_vector *x
       }
     } else {
     MK_TRY(launch_spmv_dot(A, S->p, S->s, S->slab1, &S->state->done, &nb1));
+    stamp(it);
     if (dinv) {
       hipLaunchKernelGGL((pcg_update_xr_kernel<true>), dim3(vb), dim3(kVecThreads), 0, c.stream, n, S->p, S->s, dinv, x->d, S->r, S->slab1, nb1, kSlabStride, S->slab2, S->state, (int)nt_rows(n));
+      stamp(it);
       hipLaunchKernelGGL((pcg_update_p_kernel<true>), dim3(vb), dim3(kVecThreads), 0, c.stream, n, S->r, dinv, S->p, S->slab2, vb, kSlabStride, S->two_norm, S->rel_change, S->state, S->norms, (int)nt_rows(n));
     } else {
       hipLaunchKernelGGL((pcg_update_xr_kernel<false>), dim3(vb), dim3(kVecThreads), 0, c.stream, n, S->p, S->s, dinv, x->d, S->r, S->slab1, nb1, kSlabStride, S->slab2, S->state, (int)nt_rows(n));
+      stamp(it);
       hipLaunchKernelGGL((pcg_update_p_kernel<false>), dim3(vb), dim3(kVecThreads), 0, c.stream, n, S->r, dinv, S->p, S->slab2, vb, kSlabStride, S->two_norm, S->rel_change, S->state, S->norms, (int)nt_rows(n));
     }
     }
@@ -177,6 +202,7 @@ int mk_pcg_solve(mk_pcg *S, const mk_matrix *A, const mk_vector *b, mk_vector *x
       }
     }
   }
+  if (tev_used > 0 && tev_used == timed_iters * nslots) (void)hipEventRecord(S->tev[tev_used++], c.stream);   // solve ended with the timed window
   if (fuse_p && S->max_iter > 0)   // the test that the next step's first kernel would have made (K3's prologue; n = 0: no p update)
     hipLaunchKernelGGL((pcg_update_p_kernel<false>), dim3(1), dim3(kVecThreads), 0, c.stream, (int64_t)0, S->r, (const double *)nullptr, pcur, S->slab2, nb2, kSlabStride, S->two_norm, S->rel_change, S->state, S->norms, 0);
   MK_HIP(hipGetLastError());
@@ -186,6 +212,18 @@ int mk_pcg_solve(mk_pcg *S, const mk_matrix *A, const mk_vector *b, mk_vector *x
   S->converged = hst[0].converged;
   S->breakdown = hst[0].breakdown;
   S->rel_res_norm = sqrt(hst[0].i_prod / hst[0].bi_prod);
+  if (S->timing) {
+    S->kt_slots = nslots;
+    for (int k = 0; k < mk_pcg::kTimedSlots; k++) { S->kt_ms[k] = 0.0; S->kt_launches[k] = 0; }
+    // only iterations that ran to their end: an early stop leaves later events unrecorded or around no-op kernels
+    const long long ran = std::min<long long>(hst[0].iter - 1, timed_iters);
+    if (tev_used == timed_iters * nslots + 1)
+      for (long long i = 0; i < ran; i++)
+        for (int k = 0; k < nslots; k++) {
+          float ms = 0.f;
+          if (hipEventElapsedTime(&ms, S->tev[i * nslots + k], S->tev[i * nslots + k + 1]) == hipSuccess) { S->kt_ms[k] += ms; S->kt_launches[k]++; }
+        }
+  }
   if (S->print_level > 1) {
     // same three facts HYPRE's print level reports per solve; per-iteration table omitted
     printf("PCG: %lld iterations, relative residual %e%s\n", S->iterations, S->rel_res_norm,
@@ -203,6 +241,17 @@ int mk_pcg_get_num_iterations(const mk_pcg *S, long long *iterations) {
 int mk_pcg_get_final_relative_residual_norm(const mk_pcg *S, double *norm) {
   if (!S || !norm) return fail(MK_ERR_INVALID, "mk_pcg_get_final_relative_residual_norm: null argument");
   *norm = S->rel_res_norm;
+  return MK_OK;
+}
+
+int mk_pcg_get_kernel_timing(const mk_pcg *S, int *nslots, double *avg_ms, long long *launches, int capacity) {
+  if (!S || !nslots || !avg_ms || !launches || capacity < mk_pcg::kTimedSlots) return fail(MK_ERR_INVALID, "mk_pcg_get_kernel_timing: bad argument (capacity >= 3)");
+  if (!S->timing) return fail(MK_ERR_INVALID, "mk_pcg_get_kernel_timing: kernel timing was not switched on");
+  *nslots = S->kt_slots;
+  for (int k = 0; k < mk_pcg::kTimedSlots; k++) {
+    launches[k] = S->kt_launches[k];
+    avg_ms[k] = S->kt_launches[k] ? S->kt_ms[k] / (double)S->kt_launches[k] : 0.0;
+  }
   return MK_OK;
 }
 
@@ -292,7 +341,9 @@ int mk_jacobi_solve(mk_jacobi *S, const mk_matrix *A, const mk_vector *b, mk_vec
   hipLaunchKernelGGL(jacobi_init_kernel, dim3(1), dim3(256), 0, c.stream, S->slab, vb, kSlabStride, S->tol, S->state);
   MK_HIP(hipMemcpyAsync(hst, S->state, sizeof(JacobiState), hipMemcpyDeviceToHost, c.stream));
   MK_HIP(hipStreamSynchronize(c.stream));
-  if (!(hst->bb > 0.0)) {
+  if (!std::isfinite(hst->bb) || hst->bb < 0.0)
+    return fail(MK_ERR_INVALID, "mk_jacobi_solve: <b,b> = %g: NaN or Inf in the right-hand side", hst->bb);
+  if (hst->bb == 0.0) {
     hipLaunchKernelGGL(copy_kernel, dim3(vb), dim3(256), 0, c.stream, x->d, b->d, n);
     MK_HIP(hipStreamSynchronize(c.stream));
     return MK_OK;

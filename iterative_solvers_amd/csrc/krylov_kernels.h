@@ -7,6 +7,7 @@
 #include "mk_internal.h"
 
 #include <type_traits>
+#include <vector>
 namespace mk {
 
 constexpr int kVecThreads = 256;
@@ -45,7 +46,7 @@ static __global__ __launch_bounds__(kVecThreads) void pcg_init_scalars_kernel(co
     s.gamma = v[1];
     s.i_prod = two_norm ? v[2] : v[1];
     s.eps = tol * tol;
-    s.done = (v[0] > 0.0) ? 0 : 1;  // zero right-hand side: x = b, nothing to iterate
+    s.done = (v[0] > 0.0) ? 0 : 1;  // zero (or NaN) right-hand side: nothing to iterate, the host decides which it was
     *st = s;
     if (norms) norms[0] = (v[0] > 0.0) ? sqrt(s.i_prod / v[0]) : 0.0;
   }
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(kVecThreads) void pcg_update_xr_kernel(int64_t n, c
                                                                     double *__restrict__ x, double *__restrict__ r,
                                                                     const double *__restrict__ slab_in, int nblocks_in, int stride_in,
                                                                     double *__restrict__ slab_out, PcgState *st, int nt) {
-  if (st->done != 0) return;
+  if (block_flag_raised(&st->done)) return;
   __shared__ double smem[3 * (kVecThreads / 64)];
   double d[2];
   reduce_slab<2, kVecThreads>(slab_in, nblocks_in, stride_in, d, smem);
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(kVecThreads) void pcg_update_p_kernel(int64_t n, co
                                                                    const double *__restrict__ slab_in, int nblocks_in, int stride_in,
                                                                    int two_norm, int rel_change, PcgState *st,
                                                                    double *__restrict__ norms, int nt) {
-  if (st->done != 0) return;
+  if (block_flag_raised(&st->done)) return;
   __shared__ double smem[3 * (kVecThreads / 64)];
   double d[3];
   reduce_slab<3, kVecThreads>(slab_in, nblocks_in, stride_in, d, smem);
@@ -234,6 +235,14 @@ struct mk_pcg {
   double *norms = nullptr;
   int norms_cap = 0;
   hipEvent_t ev[2] = {nullptr, nullptr};
+  // kernel timing (mk_pcg_set_kernel_timing): one HIP event in front of every kernel of iterations 2..kTimedIters+1
+  // of a solve and one behind the last; slot k = k-th kernel of a step
+  static constexpr int kTimedIters = 32, kTimedSlots = 3;
+  int timing = 0;
+  std::vector<hipEvent_t> tev;
+  double kt_ms[kTimedSlots] = {0.0, 0.0, 0.0};
+  long long kt_launches[kTimedSlots] = {0, 0, 0};
+  int kt_slots = 0;
   // results
   long long iterations = 0;
   double rel_res_norm = 0.0;

@@ -249,6 +249,17 @@ __device__ __forceinline__ void block_sum(double (&v)[NP], double *smem /* NP*(T
   __syncthreads();
 }
 
+// Block-uniform read of a stop flag.  The leader of block 0 may raise the flag inside the same launch (breakdown,
+// convergence); waves of one block that read it themselves could then disagree, one leaving while its siblings go
+// on into a block-wide reduction over LDS slots that were never written.  One thread reads, everybody takes its
+// answer.  Call at most once per kernel, before any other use of shared memory is in flight.
+__device__ __forceinline__ bool block_flag_raised(const int *flag) {
+  __shared__ int sh_flag;
+  if (threadIdx.x == 0) sh_flag = *flag;
+  __syncthreads();
+  return sh_flag != 0;
+}
+
 // Vectors of this many rows no longer stay in the 256 MB Infinity Cache between the kernels of an iteration
 // (4 vectors x 8 B x 10 M rows = 320 MB): single-use streams then go nontemporal.  Measured crossover on the sweep
 // path and on the K2/K3 vector kernels alike: 8.4 M rows default policy 2 % ahead, 16.7 M rows nontemporal 5-9 % ahead.

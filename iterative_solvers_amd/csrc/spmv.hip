@@ -1073,7 +1073,7 @@ __global__ __launch_bounds__(T, T == 512 ? 2 : 1) void spmv_sweep_kernel(
   unsigned *smask = reinterpret_cast<unsigned *>(ring + NS * sw);   // npat
   const int tid = threadIdx.x;
   if (MODE >= 3) {
-    if (st->done != 0) return;
+    if (block_flag_raised(&st->done)) return;
     if (MODE == 4) {   // K2's prologue
       const bool leader = (blockIdx.x == 0 && tid == 0);
       double d[2];

@@ -24,6 +24,7 @@ def _lib():
         L.mk_comm_create_local.argtypes = [C.c_int, C.POINTER(P)]
         L.mk_comm_destroy.argtypes = [P]
         L.mk_comm_self_test.argtypes = [P]
+        L.mk_comm_all_reduce_host.argtypes = [P, np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS"), C.c_int, C.c_int]
         L.mk_dist_matrix_create.argtypes = [P, C.c_int64, P, P, C.POINTER(P)]
         L.mk_dist_matrix_destroy.argtypes = [P]
         L.mk_dist_matrix_get_info.argtypes = [P] + [C.POINTER(C.c_int64)] * 5 + [C.POINTER(C.c_int)]
@@ -36,7 +37,7 @@ def _lib():
     return L
 
 
-DIST_EXPORTS = ["mk_comm_get_unique_id", "mk_comm_create", "mk_comm_create_local", "mk_comm_self_test", "mk_comm_destroy",
+DIST_EXPORTS = ["mk_comm_get_unique_id", "mk_comm_create", "mk_comm_create_local", "mk_comm_self_test", "mk_comm_all_reduce_host", "mk_comm_destroy",
                 "mk_dist_matrix_create", "mk_dist_matrix_destroy", "mk_dist_matrix_get_info", "mk_dist_matrix_set_spmv_kernel",
                 "mk_dist_vector_create", "mk_dist_spmv", "mk_dist_pcg_solve", "mk_dist_jacobi_solve"]
 
@@ -97,6 +98,12 @@ class Comm:
 
     def self_test(self):
         _ck(_lib().mk_comm_self_test(self.h))
+
+    def all_reduce_host(self, values, op="sum"):
+        """MPI_Allreduce of a few host doubles (solvers.c:760 takes the max of the solve times this way)"""
+        v = np.ascontiguousarray(values, dtype=np.float64).copy()
+        _ck(_lib().mk_comm_all_reduce_host(self.h, v, v.size, 1 if op == "max" else 0))
+        return v
 
     @classmethod
     def local_world(cls, nranks):
@@ -196,12 +203,12 @@ def bench_main(args, rank, local_rank, world, workloads, hbm_peak):
     import torch
     import torch.distributed as dist
     name = args.workload or "lap7_512_cg"
-    kind, nx, ny, nz, precond, desc = workloads[name]
+    kind, nx, ny, nz, precond, seed, desc = workloads[name]
     n = nx * ny * nz
     rs = slab_row_start(nx, ny, nz, world)
     comm = Comm.from_torch()
     comm.self_test()
-    block = Matrix.stencil(kind, nx, ny, nz, row_begin=int(rs[rank]), row_end=int(rs[rank + 1]))
+    block = Matrix.stencil(kind, nx, ny, nz, row_begin=int(rs[rank]), row_end=int(rs[rank + 1]), scale_seed=seed)
     local_nnz = block.nnz
     A = DistMatrix(block, n, rs, comm)
     info = A.info()

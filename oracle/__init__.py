@@ -62,6 +62,8 @@ def lib():
                                    _i32p, _i32p, _f64p]
         L.orc_stencil_csr.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_stencil_csr.restype = C.c_int64
+        L.orc_row_scale.argtypes = [C.c_uint64, C.c_int64, C.c_int64, _f64p]
+        L.orc_csr_scale_sym.argtypes = [C.c_uint32, _i32p, _i32p, _f64p, _f64p]
         L.orc_banded_csr.argtypes = [C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_banded_csr.restype = C.c_int64
         _lib = L
@@ -185,11 +187,24 @@ def rmat_coo(scale, nedges, seed=42, a=0.57, b=0.19, c=0.19):
     return r, cc, v
 
 
-def stencil_csr(kind, nx, ny, nz=1):
+def row_scale(seed, n, row_begin=0):
+    s = np.empty(n)
+    lib().orc_row_scale(seed, row_begin, n, s)
+    return s
+
+
+def num_threads():
+    return int(lib().orc_num_threads())
+
+
+def stencil_csr(kind, nx, ny, nz=1, scale_seed=None):
+    """scale_seed: D A D with the per-row scale of mk_matrix_generate_stencil_scaled (variable coefficients)"""
     nnz = lib().orc_stencil_csr(kind, nx, ny, nz, None, None, None)
     n = nx * ny * (1 if kind == 5 else nz)
     rp, ci, v = np.empty(n + 1, np.int32), np.empty(nnz, np.int32), np.empty(nnz, np.float64)
     lib().orc_stencil_csr(kind, nx, ny, nz, rp.ctypes.data, ci.ctypes.data, v.ctypes.data)
+    if scale_seed is not None:
+        lib().orc_csr_scale_sym(n, rp, ci, v, row_scale(scale_seed, n))
     return rp, ci, v
 
 

@@ -395,13 +395,54 @@ void orc_rmat_coo(int scale, uint64_t nedges, uint64_t seed, double a, double b,
   }
 }
 
+int orc_num_threads(void) { return omp_get_max_threads(); }
+
+/* row scale of the variable-coefficient operators (iterative_solvers_amd/csrc/generate.hip row_scale holds the same
+ * definition): a 13-bit dyadic rational in [1, 5), so (a_ij * s_i) * s_j is exact in fp64 */
+void orc_row_scale(uint64_t seed, int64_t row_begin, int64_t n, double *s) {
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; i++) {
+    const uint64_t h = orc_splitmix64(seed ^ ((uint64_t)(row_begin + i) * 0xD1B54A32D192ED03ULL));
+    s[i] = (double)(1024 + (int)(h >> 52)) * (1.0 / 1024.0);
+  }
+}
+
+/* val <- D val D, D = diag(s) */
+void orc_csr_scale_sym(uint32_t n, const int *rowptr, const int *col, double *val, const double *s) {
+#pragma omp parallel for schedule(static)
+  for (int64_t r = 0; r < (int64_t)n; r++)
+    for (int k = rowptr[r]; k < rowptr[r + 1]; k++) val[k] = (val[k] * s[r]) * s[col[k]];
+}
+
+static int stencil_len(int kind, int nx, int ny, int nz, int ix, int iy, int iz) {
+  const int cx = 1 + (ix > 0) + (ix < nx - 1), cy = 1 + (iy > 0) + (iy < ny - 1), cz = 1 + (iz > 0) + (iz < nz - 1);
+  return kind == 27 ? cx * cy * cz : kind == 7 ? cx + cy + cz - 2 : cx + cy - 1;
+}
+
 int64_t orc_stencil_csr(int kind, int nx, int ny, int nz, int *rowptr, int *col, double *val) {
   if (kind == 5) nz = 1;
   const int64_t n = (int64_t)nx * ny * nz;
-  int64_t k = 0;
+  if (!col) {   /* size query */
+    int64_t total = 0;
+#pragma omp parallel for reduction(+ : total) schedule(static)
+    for (int64_t row = 0; row < n; row++)
+      total += stencil_len(kind, nx, ny, nz, (int)(row % nx), (int)((row / nx) % ny), (int)(row / ((int64_t)nx * ny)));
+    return total;
+  }
+  /* row pointers first (serial prefix), then the rows are filled by all threads under the same static schedule as the
+   * OpenMP product, so that on a NUMA host every thread finds its rows in its own memory (bench.py's cpu_baseline) */
+  {
+    int64_t k = 0;
+    for (int64_t row = 0; row < n; row++) {
+      rowptr[row] = (int)k;
+      k += stencil_len(kind, nx, ny, nz, (int)(row % nx), (int)((row / nx) % ny), (int)(row / ((int64_t)nx * ny)));
+    }
+    rowptr[n] = (int)k;
+  }
+#pragma omp parallel for schedule(static)
   for (int64_t row = 0; row < n; row++) {
     const int ix = (int)(row % nx), iy = (int)((row / nx) % ny), iz = (int)(row / ((int64_t)nx * ny));
-    if (rowptr) rowptr[row] = (int)k;
+    int64_t k = rowptr[row];
     if (kind == 27) {
       for (int dz = -1; dz <= 1; dz++)
         for (int dy = -1; dy <= 1; dy++)
@@ -430,8 +471,7 @@ int64_t orc_stencil_csr(int kind, int nx, int ny, int nz, int *rowptr, int *col,
       }
     }
   }
-  if (rowptr) rowptr[n] = (int)k;
-  return k;
+  return rowptr[n];
 }
 
 int64_t orc_banded_csr(int64_t n, int hb, int *rowptr, int *col, double *val) {

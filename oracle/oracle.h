@@ -99,6 +99,10 @@ void orc_rmat_coo(int scale, uint64_t nedges, uint64_t seed, double a, double b,
 /* stencil CSR, lexicographic x fastest: kind 5 (2D 5-pt), 7 (3D 7-pt), 27 (3D 27-pt).
  * returns nnz; pass NULL arrays to count only. */
 int64_t orc_stencil_csr(int kind, int nx, int ny, int nz, int *rowptr, int *col, double *val);
+/* variable coefficients: D A D with the per-row scale of generate.hip row_scale (13-bit dyadic rational in [1, 5)) */
+void orc_row_scale(uint64_t seed, int64_t row_begin, int64_t n, double *s);
+void orc_csr_scale_sym(uint32_t n, const int *rowptr, const int *col, double *val, const double *s);
+int orc_num_threads(void);
 /* banded matrix, half bandwidth hb, diagonal 2*hb+1, off-diagonals -1 */
 int64_t orc_banded_csr(int64_t n, int hb, int *rowptr, int *col, double *val);
 

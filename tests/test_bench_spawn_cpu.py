@@ -1,0 +1,26 @@
+"""bench.py --gpus N started without a launcher must start its own ranks: rehearsed on CPU with
+MK_BENCH_DRY_SPAWN=1 (gloo rendezvous, broadcast of the communicator id bytes, barrier, rank 0's JSON line relayed)."""
+import json
+import os
+import subprocess
+import sys
+
+from conftest import ROOT
+
+
+def test_bench_starts_its_own_ranks():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["MK_BENCH_DRY_SPAWN"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j == {"dry_run": True, "n_gpus": 2, "max_rank": 1.0, "id_ok": True, "steps": 3, "warmup": 1}
+
+
+def test_bench_refuses_a_mismatched_launcher():
+    env = dict(os.environ, WORLD_SIZE="3", RANK="0", MK_BENCH_DRY_SPAWN="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0 and "WORLD_SIZE=3" in out.stderr

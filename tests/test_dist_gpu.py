@@ -122,6 +122,70 @@ def test_dist_pcg_fused_sweep_step(world, precond):
     assert np.allclose(np.concatenate([x.get() for x in xs2]), o2["x"], rtol=1e-9, atol=1e-13)
 
 
+@pytest.mark.parametrize("world,precond,sweep", [(2, 0, False), (2, 1, True), (4, 0, True), (4, 1, False), (8, 0, True), (8, 1, True)])
+def test_dist_27pt_rowblock_cg(world, precond, sweep):
+    """BASELINE configs[3] scaled down: 27-point stencil, z-slab row blocks (solvers.c:214-281), CG.  The off-rank rows of
+    a slab face hold 9 entries each (two lanes per row in the off-rank kernel); diag blocks on the default kernel and on
+    the sweep kernel (fused step)."""
+    dims = (16, 18, 24)
+    rp, ci, v = oracle.stencil_csr(27, *dims)
+    n = rp.size - 1
+    rng = np.random.default_rng(27 + world)
+    rs = mkd.slab_row_start(*dims, world)
+    comms = mkd.Comm.local_world(world)
+    As = _blocks(rp, ci, v, n, rs, comms)
+    if sweep:
+        for A in As:
+            A.set_spmv_kernel(mk.SPMV_SWEEP)
+    i1 = As[1].info()
+    plane = dims[0] * dims[1]
+    assert i1["n_ghost"] == (2 if world > 2 else 1) * plane and i1["n_offd_rows"] == i1["n_ghost"]
+    assert i1["nnz_offd"] == i1["n_ghost"] // plane * (3 * dims[0] - 2) * (3 * dims[1] - 2)     # 9 per interior face row
+    # product
+    xh = rng.normal(size=n)
+    xs = [A.vector(values=xh[rs[r]:rs[r + 1]]) for r, A in enumerate(As)]
+    ys = [A.vector(fill=-3.0) for A in As]
+    mkd.dist_spmv(As, xs, ys)
+    got = np.concatenate([y.get() for y in ys])
+    ref = oracle.csr_spmv(rp, ci, v, xh)
+    mag = oracle.csr_spmv(rp, ci, np.abs(v), np.abs(xh))
+    assert (np.abs(got - ref) / mag).max() <= 1e-12
+    # solve
+    bh = rng.normal(size=n)
+    o = oracle.pcg(rp, ci, v, bh, tol=1e-9, precond=precond, maxit=2000, want_norms=True)
+    bs = [A.vector(values=bh[rs[k]:rs[k + 1]]) for k, A in enumerate(As)]
+    xs = [A.vector(fill=0.0) for A in As]
+    Ss = [mk.PCG(max_iter=2000, tol=1e-9, precond=precond, logging=1, check_every=7) for _ in As]
+    res = mkd.dist_pcg_solve(Ss, As, bs, xs)
+    assert all(q == res[0] for q in res)
+    assert res[0]["converged"] == 1 and abs(res[0]["iterations"] - o["iterations"]) <= 2
+    xg = np.concatenate([x.get() for x in xs])
+    assert np.linalg.norm(xg - o["x"]) <= 1e-6 * np.linalg.norm(o["x"])
+    hist = Ss[0].residual_history(4000)
+    m = min(hist.size, o["rel_norms"].size, 30)
+    assert np.allclose(hist[:m], o["rel_norms"][:m], rtol=1e-8)
+    # exactly k iterations
+    xs2 = [A.vector(fill=0.0) for A in As]
+    S2 = [mk.PCG(max_iter=4, tol=1e-30, precond=precond) for _ in As]
+    r2 = mkd.dist_pcg_solve(S2, As, bs, xs2)
+    o2 = oracle.pcg(rp, ci, v, bh, tol=1e-30, precond=precond, maxit=4)
+    assert r2[0]["iterations"] == 4
+    assert np.allclose(np.concatenate([x.get() for x in xs2]), o2["x"], rtol=1e-9, atol=1e-13)
+
+
+def test_dist_pcg_rejects_nan_rhs():
+    rp, ci, v = oracle.stencil_csr(5, 12, 12)
+    n = rp.size - 1
+    rs = mkd.even_row_start(n, 2)
+    As = _blocks(rp, ci, v, n, rs, mkd.Comm.local_world(2))
+    bh = np.ones(n)
+    bh[5] = np.nan
+    bs = [A.vector(values=bh[rs[k]:rs[k + 1]]) for k, A in enumerate(As)]
+    xs = [A.vector(fill=0.0) for A in As]
+    with pytest.raises(mk.MkError, match="NaN or Inf"):
+        mkd.dist_pcg_solve([mk.PCG(max_iter=5) for _ in As], As, bs, xs)
+
+
 def test_dist_pcg_maxit_and_empty_rank():
     rp, ci, v = oracle.stencil_csr(5, 20, 20)
     n = rp.size - 1

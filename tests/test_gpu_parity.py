@@ -740,6 +740,18 @@ def test_pcg_maxit_zero_rhs_and_restart():
     b0 = mk.Vector(n, fill=0.0)
     res0 = S.solve(A, b0, x)
     assert res0["iterations"] == 0 and np.all(x.get() == 0.0)
+    # NaN / Inf in b or x0 is an error (hypre_PCGSolve's ieee_check), not a zero right-hand side
+    for bad in (np.nan, np.inf):
+        bh = np.ones(n)
+        bh[n // 2] = bad
+        with pytest.raises(mk.MkError, match="NaN or Inf"):
+            S.solve(A, mk.Vector(n, values=bh), mk.Vector(n, fill=0.0))
+    with pytest.raises(mk.MkError, match="NaN or Inf"):
+        S.solve(A, b, mk.Vector(n, values=np.where(np.arange(n) == 3, np.nan, 0.0)))
+    J = mk.Jacobi(max_iter=5)
+    J.setup(A, b, x)
+    with pytest.raises(mk.MkError, match="NaN or Inf"):
+        J.solve(A, mk.Vector(n, values=np.where(np.arange(n) == 3, np.nan, 1.0)), mk.Vector(n, fill=0.0))
 
 
 def test_pcg_tol_zero_runs_exactly_maxit():

@@ -139,6 +139,80 @@ def test_csr_cache_round_trip(tmp_path):
     assert L.read_csr_cache(str(tmp_path / "absent").encode(), C.byref(r)) != 0
 
 
+def test_csr_cache_checks_values_and_source_file(tmp_path):
+    """the checksum covers the value bytes, and a cache made from a .mtx that has changed since is refused"""
+    L = _host()
+    for f in (L.write_csr_cache_for, L.read_csr_cache_for):
+        f.argtypes = [C.c_char_p, C.POINTER(mk.CSR), C.c_char_p]
+    g = np.load(os.path.join(GOLDEN, "poisson5_6x5_sorted.npz"))
+    rp, ci, v = (np.ascontiguousarray(g[k]) for k in ("csr_rowptr", "csr_col", "csr_val"))
+    m = mk.CSR(v.ctypes.data_as(C.POINTER(C.c_double)), ci.ctypes.data_as(C.POINTER(C.c_int)),
+               rp.ctypes.data_as(C.POINTER(C.c_int)), int(g["nrows"]), int(g["ncols"]), ci.size)
+    src = tmp_path / "a.mtx"
+    src.write_text(open(os.path.join(GOLDEN, "poisson5_6x5_sorted.mtx")).read())
+    path = str(tmp_path / "a.mtx.mkcsr").encode()
+    assert L.write_csr_cache_for(path, C.byref(m), str(src).encode()) == 0
+    r = mk.CSR()
+    assert L.read_csr_cache_for(path, C.byref(r), str(src).encode()) == 0
+    assert L.read_csr_cache_for(path, C.byref(r), None) == 0
+    # same size, later modification time: stale
+    st = os.stat(src)
+    os.utime(src, ns=(st.st_atime_ns, st.st_mtime_ns + 2_000_000_000))
+    assert L.read_csr_cache_for(path, C.byref(r), str(src).encode()) == 4
+    os.utime(src, ns=(st.st_atime_ns, st.st_mtime_ns))
+    assert L.read_csr_cache_for(path, C.byref(r), str(src).encode()) == 0
+    src.write_text(src.read_text() + "\n")                 # other size
+    assert L.read_csr_cache_for(path, C.byref(r), str(src).encode()) == 4
+    # one flipped bit in a value, two values swapped: both fail the checksum
+    raw = bytearray(open(path, "rb").read())
+    pad64 = lambda b: (b + 63) // 64 * 64
+    voff = 64 + pad64(4 * (m.nrows + 1)) + pad64(4 * m.nnz)
+    bad = bytearray(raw)
+    bad[voff + 8 * 3] ^= 1
+    open(path, "wb").write(bad)
+    assert L.read_csr_cache_for(path, C.byref(r), None) == 3
+    bad = bytearray(raw)
+    bad[voff:voff + 8], bad[voff + 16:voff + 24] = raw[voff + 16:voff + 24], raw[voff:voff + 8]    # -1 and 4: differ
+    assert bad != raw
+    open(path, "wb").write(bad)
+    assert L.read_csr_cache_for(path, C.byref(r), None) == 3
+
+
+@pytest.mark.parametrize("name", ["random_70k", "ragged_dups_empty_rows", "skewed_one_long_row", "empty_matrix"])
+@pytest.mark.parametrize("np_ranks", [1, 2, 5])
+def test_row_block_slicing_of_the_np_driver(name, np_ranks):
+    """host side of `solver -np N` (solvers.c:214-281 without its defects): row pointers of the unsorted COO, the cuts
+    of mk_partition_rows, and each rank's entries in input order with rows renumbered from 0"""
+    L = _host()
+    L.coo_row_pointers64.argtypes = [C.POINTER(mk.COO), np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")]
+    L.slice_coo_rows.argtypes = [C.POINTER(mk.COO), C.c_longlong, C.c_longlong, C.POINTER(mk.COO)]
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    rows, cols, vals = g["coo_rows"], g["coo_cols"], g["coo_vals"]
+    n = int(g["nrows"])
+    src = mk._coo_struct(n, int(g["ncols"]), rows, cols, vals)
+    rp = np.zeros(n + 1, np.int64)
+    assert L.coo_row_pointers64(C.byref(src), rp) == 0
+    assert np.array_equal(rp, g["csr_rowptr"].astype(np.int64))              # the reference's own row pointers
+    rs = mk.partition_rows(rp, np_ranks)
+    assert np.array_equal(rs, oracle.partition_rows(rp, np_ranks)) and rs[0] == 0 and rs[-1] == n
+    seen = 0
+    for r in range(np_ranks):
+        lo, hi = int(rs[r]), int(rs[r + 1])
+        out = mk.COO()
+        assert L.slice_coo_rows(C.byref(src), lo, hi, C.byref(out)) == 0
+        keep = (rows >= lo) & (rows < hi)
+        assert (out.nrows, out.ncolumns, out.nnz) == (hi - lo, int(g["ncols"]), int(keep.sum()))
+        k = out.nnz
+        if k:
+            assert np.array_equal(np.ctypeslib.as_array(out.rows, (k,)), rows[keep] - lo)
+            assert np.array_equal(np.ctypeslib.as_array(out.columns, (k,)), cols[keep])
+            assert np.array_equal(np.ctypeslib.as_array(out.values, (k,)).view(np.uint64), vals[keep].view(np.uint64))
+        seen += k
+    assert seen == rows.size
+    bad = mk.COO()
+    assert L.slice_coo_rows(C.byref(src), 3, 2, C.byref(bad)) != 0 and L.slice_coo_rows(C.byref(src), 0, n + 1, C.byref(bad)) != 0
+
+
 def test_loader_errors_are_returned_not_fatal(tmp_path):
     L = _host()
     m = mk.COO()
@@ -299,3 +373,59 @@ def test_driver_jacobi_and_vector_files(tmp_path):
     it = int(re.search(r"^Iterations = (\d+)$", out.stdout, re.M).group(1))
     o = oracle.jacobi(rp, ci, v, bh, tol=1e-9, maxit=300, check_every=10)
     assert it == o["iterations"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("solver,precond", [(50, 0), (51, 1), (70, None)])
+def test_driver_row_block_path_one_rank(tmp_path, solver, precond):
+    """`solver -dist`: the np > 1 code path of the driver (slice, mk_dist_matrix_create over a real RCCL communicator,
+    mk_dist_*_solve, all-reduced wall time) with a world of one rank -- RCCL refuses two ranks on one GPU"""
+    mtx = tmp_path / "poisson.mtx"
+    if solver == 70:
+        n = 2000
+        rp, ci, v = oracle.banded_csr(n, 3)
+        rows = np.repeat(np.arange(n), np.diff(rp))
+        with open(mtx, "w") as f:
+            f.write("%%MatrixMarket matrix coordinate real general\n" + f"{n} {n} {rows.size}\n")
+            for k in np.random.default_rng(0).permutation(rows.size):
+                f.write(f"{rows[k] + 1} {ci[k] + 1} {v[k]}\n")
+        o = oracle.jacobi(rp, ci, v, np.ones(n), tol=1e-8, maxit=500, check_every=10)
+    else:
+        rp, ci, v = _write_poisson(mtx, 56, 40, shuffle_seed=6)
+        o = oracle.pcg(rp, ci, v, np.ones(rp.size - 1), tol=1e-8, precond=precond, maxit=500)
+    out = subprocess.run([os.path.join(HOST, "solver"), "-solver", str(solver), "-mtx", str(mtx), "-tol", "1e-8", "-maxit", "500",
+                          "-log", "0", "-dist", "-id_file", str(tmp_path / "id.bin"), "-print_system"],
+                         capture_output=True, text=True, timeout=180, cwd=tmp_path)
+    assert out.returncode == 0, out.stderr
+    assert re.search(r"^(PCG|Jacobi) Solve time = [0-9.]+ seconds$", out.stdout, re.M) and "Ranks = 1" in out.stdout
+    it = int(re.search(r"^Iterations = (\d+)$", out.stdout, re.M).group(1))
+    nrm = float(re.search(r"^Final Relative Residual Norm = ([0-9.e+-]+)$", out.stdout, re.M).group(1))
+    assert abs(it - o["iterations"]) <= (0 if solver == 70 else 2) and nrm < 1e-8
+    assert not os.path.exists(tmp_path / "id.bin")          # rank 0 removes the rendezvous file
+    # -print_system: HYPRE's IJ print layout, one file per rank (solvers.c:450-454)
+    a = open(tmp_path / "IJ.out.A.00000").read().split("\n")
+    n = rp.size - 1
+    assert a[0].split() == ["0", str(n - 1), "0", str(n - 1)] and len(a) - 2 == ci.size
+    trip = np.array([l.split() for l in a[1:-1]], dtype=float)
+    # the driver hands the COO of the file to the device sort: stable by row, so row r holds the file's order
+    assert np.array_equal(trip[:, 0].astype(int), np.repeat(np.arange(n), np.diff(rp)))
+    bfile = open(tmp_path / "IJ.out.b.00000").read().split("\n")
+    assert bfile[0].split() == ["0", str(n - 1)] and float(bfile[1].split()[1]) == 1.0 and len(bfile) - 2 == n
+    assert os.path.exists(tmp_path / "IJ.out.x.00000")
+
+
+@pytest.mark.gpu
+def test_driver_rejects_stale_cache(tmp_path):
+    mtx = tmp_path / "poisson.mtx"
+    _write_poisson(mtx, 20, 20)
+    run = lambda: subprocess.run([os.path.join(HOST, "solver"), "-solver", "50", "-mtx", str(mtx), "-cache", "-tol", "1e-9", "-log", "0"],
+                                 capture_output=True, text=True, timeout=120)
+    first = run()
+    assert first.returncode == 0 and os.path.exists(str(mtx) + ".mkcsr")
+    _write_poisson(mtx, 24, 20)                             # another matrix under the same name
+    second = run()
+    assert second.returncode == 0 and "Loaded binary CSR cache" not in second.stderr
+    third = run()
+    assert "Loaded binary CSR cache" in third.stderr
+    pick = lambda o: re.findall(r"^(Iterations = \d+|Final Relative Residual Norm = \S+)$", o.stdout, re.M)
+    assert pick(second) == pick(third) != pick(first)
