@@ -162,6 +162,15 @@ int mk_spmv(const mk_matrix *A, double alpha, const mk_vector *x, double beta, m
  * outputs NULL the kernel is only enqueued (no read-back, no synchronisation). */
 int mk_spmv_dot(const mk_matrix *A, const mk_vector *x, mk_vector *y, double *ytx, double *xtx);
 
+/* mk_spmv_dot without any allocation.  No counterpart in the reference: it is for callers that cannot allocate device
+ * memory at the point of the call (HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).  All scratch
+ * of its kernels (reduction partials, the two results, the split kernel's carry pairs) is a file-scope device array of
+ * 592 KB per GPU; the call uses no hipMalloc, hipFree or library-allocated scratch.  Conditions: the matrix has been
+ * analysed (mk_matrix_get_info, which allocates, was called once; for split-kernel matrices one mk_spmv / mk_spmv_dot
+ * has run); split-kernel matrices hold at most 2^26 entries -- larger ones are rejected with MK_ERR_UNSUPPORTED.
+ * Results are bitwise those of mk_spmv_dot.  All calls on one GPU share the array: calls that overlap on one GPU race. */
+int mk_spmv_dot_static(const mk_matrix *A, const mk_vector *x, mk_vector *y, double *ytx, double *xtx);
+
 /* ---- PCG: HYPRE_ParCSRPCG* / HYPRE_PCG* (solvers.c:729-775) ------------------------------ */
 typedef enum { MK_PRECOND_NONE = 0, MK_PRECOND_JACOBI = 1 } mk_precond;
 int mk_pcg_create(mk_pcg **solver);                               /* HYPRE_ParCSRPCGCreate :729 */

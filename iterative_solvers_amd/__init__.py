@@ -50,7 +50,7 @@ EXPORTS = [
     "mk_matrix_generate_stencil", "mk_matrix_generate_stencil_scaled", "mk_matrix_generate_banded", "mk_coo_generate_rmat",
     "mk_coo_from_host", "mk_coo_download", "mk_coo_destroy",
     "mk_vector_create", "mk_vector_set", "mk_vector_fill", "mk_vector_get", "mk_vector_destroy",
-    "mk_vector_size", "mk_spmv", "mk_spmv_dot",
+    "mk_vector_size", "mk_spmv", "mk_spmv_dot", "mk_spmv_dot_static",
     "mk_pcg_create", "mk_pcg_set_max_iter", "mk_pcg_set_tol", "mk_pcg_set_two_norm",
     "mk_pcg_set_rel_change", "mk_pcg_set_print_level", "mk_pcg_set_logging", "mk_pcg_set_precond",
     "mk_pcg_set_check_every", "mk_pcg_set_kernel_timing", "mk_pcg_get_kernel_timing", "mk_pcg_setup", "mk_pcg_solve", "mk_pcg_get_num_iterations",
@@ -116,6 +116,7 @@ def load():
         "mk_vector_size": [P],
         "mk_spmv": [P, C.c_double, P, C.c_double, P],
         "mk_spmv_dot": [P, P, P, C.POINTER(C.c_double), C.POINTER(C.c_double)],
+        "mk_spmv_dot_static": [P, P, P, C.POINTER(C.c_double), C.POINTER(C.c_double)],
         "mk_pcg_create": [C.POINTER(P)], "mk_pcg_set_max_iter": [P, C.c_int], "mk_pcg_set_tol": [P, C.c_double],
         "mk_pcg_set_two_norm": [P, C.c_int], "mk_pcg_set_rel_change": [P, C.c_int],
         "mk_pcg_set_print_level": [P, C.c_int], "mk_pcg_set_logging": [P, C.c_int],
@@ -384,6 +385,12 @@ class Matrix:
             return None
         a, b = C.c_double(), C.c_double()
         _ck(load().mk_spmv_dot(self.h, x.h, y.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def spmv_dot_static(self, x, y):
+        """mk_spmv_dot_static: the same product and dots with all scratch in the library's static device array"""
+        a, b = C.c_double(), C.c_double()
+        _ck(load().mk_spmv_dot_static(self.h, x.h, y.h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
     def __del__(self):

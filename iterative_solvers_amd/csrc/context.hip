@@ -68,6 +68,7 @@ int mk_init(int device_id) {
   MK_HIP(hipHostMalloc(&c.pinned, c.pinned_bytes, hipHostMallocDefault));
   MK_TRY(dev_alloc(&c.slab, (size_t)kMaxParts * kSlabStride));
   MK_TRY(dev_alloc(&c.scalars, 8));
+  MK_TRY(init_static_scratch(device_id));   // device_id is current: every GPU has its own copy of the array
   c.ready = true;
   return MK_OK;
 }

@@ -167,6 +167,7 @@ constexpr int kSlabStride = 4096;  // >= any reduction grid we launch
 constexpr int kSplitChunk = 2048;  // entries per chunk of the split SpMV kernel
 
 int analyse_matrix(mk_matrix *A);
+int init_static_scratch(int device);   // spmv.hip: address of the file-scope scratch array of mk_spmv_dot_static on this GPU
 int ensure_dinv(mk_matrix *A);
 
 // launchers shared between translation units (all enqueue on ctx().stream)

@@ -1577,18 +1577,21 @@ static int prepare_split(mk_matrix *A) {
   return MK_OK;
 }
 
+// carry_override: the carry array to use instead of A->carry; plain_columns: original column numbering even when a
+// relabelled copy exists (both for mk_spmv_dot_static, which may touch no buffer the library allocated as scratch)
 template <int MODE>
 static int launch_split(const mk_matrix *A, double alpha, const double *x, double beta, double *y, double *slab,
-                        const int *done, int *nblocks) {
+                        const int *done, int *nblocks, double *carry_override = nullptr, bool plain_columns = false) {
   Context &c = ctx();
-  MK_TRY(prepare_split(const_cast<mk_matrix *>(A)));
+  if (!carry_override) MK_TRY(prepare_split(const_cast<mk_matrix *>(A)));
+  double *carry = carry_override ? carry_override : A->carry;
   const int main_blocks = std::max(1, std::min(A->nchunks, c.num_cus * 8));
   const int fix_blocks = std::max(1, std::min((A->nchunks + kThreads - 1) / kThreads, 1024));
   if (nblocks) *nblocks = main_blocks + fix_blocks;
   // R-MAT 2^28 entries, x = 134 MB: 3.96 -> 3.54 ms with the matrix stream nontemporal (fewer x gathers miss)
   const int *colv = A->col;
   const double *xg = x;
-  if (A->col2) {   // columns renumbered hot-first: xg[j] = x[order[j]], then the same product through col2
+  if (A->col2 && !plain_columns) {   // columns renumbered hot-first: xg[j] = x[order[j]], then the same product through col2
     hipLaunchKernelGGL(gather_x_kernel, dim3((unsigned)std::min<int64_t>((A->ncols + 255) / 256, 8192)), dim3(256), 0, c.stream,
                        A->ncols, A->xorder, x, A->xg, done);
     colv = A->col2;
@@ -1596,13 +1599,13 @@ static int launch_split(const mk_matrix *A, double alpha, const double *x, doubl
   }
   if (nt_matrix((double)A->nnz * 12.0)) {
     hipLaunchKernelGGL((spmv_split_kernel<MODE, true>), dim3(main_blocks), dim3(kThreads), 0, c.stream, A->nrows, A->nnz, A->rowptr, colv,
-                       A->val, A->chunk_row, A->nchunks, x, y, alpha, beta, A->carry, slab, done, xg);
+                       A->val, A->chunk_row, A->nchunks, x, y, alpha, beta, carry, slab, done, xg);
   } else {
     hipLaunchKernelGGL((spmv_split_kernel<MODE, false>), dim3(main_blocks), dim3(kThreads), 0, c.stream, A->nrows, A->nnz, A->rowptr, colv,
-                       A->val, A->chunk_row, A->nchunks, x, y, alpha, beta, A->carry, slab, done, xg);
+                       A->val, A->chunk_row, A->nchunks, x, y, alpha, beta, carry, slab, done, xg);
   }
   hipLaunchKernelGGL((split_fixup_kernel<MODE>), dim3(fix_blocks), dim3(kThreads), 0, c.stream, A->nrows, A->nnz, A->rowptr,
-                     A->chunk_row, A->nchunks, x, y, alpha, beta, A->carry, slab ? slab + main_blocks : nullptr, done);
+                     A->chunk_row, A->nchunks, x, y, alpha, beta, carry, slab ? slab + main_blocks : nullptr, done);
   MK_HIP(hipGetLastError());
   return MK_OK;
 }
@@ -1661,6 +1664,30 @@ int launch_spmv_dot(const mk_matrix *A, const double *x, double *y, double *slab
   return launch_vector<1>(A, 1.0, x, 0.0, y, slab, done, nblocks);
 }
 
+// ---------------------------------------------------------- the entry point that allocates nothing
+// mk_spmv_dot_static: mk_spmv_dot for callers that cannot call hipMalloc (HIP graph capture, tight serving loops).
+// Every byte of scratch its kernels need -- the slab of per-block partials, the two results, and the split kernel's
+// carry pairs -- lives in this file-scope device array instead of in buffers the library allocated.  Each GPU holds
+// its own copy (until the process ends); the host uses the address hipGetSymbolAddress gave for the current device,
+// never the array's name.
+constexpr int kStaticSlab = 2 * kSlabStride;        // partials of <y,x> and <x,x>: one slot per block, two components
+constexpr int kStaticCarryChunks = 32768;           // split kernel: carry pairs of up to 32768 chunks = 2^26 entries
+constexpr size_t kStaticDoubles = (size_t)kStaticSlab + 2 * (size_t)kStaticCarryChunks + 8;   // 592 KB per GPU
+static __device__ __align__(256) double scratch[kStaticDoubles];
+constexpr int kMaxDevices = 64;
+static double *g_scratch_ptr[kMaxDevices] = {nullptr};
+
+// called by mk_init with `device` current
+int init_static_scratch(int device) {
+  if (device < 0 || device >= kMaxDevices) return fail(MK_ERR_INVALID, "device %d: the static scratch table holds %d devices", device, kMaxDevices);
+  if (g_scratch_ptr[device]) return MK_OK;
+  double *p = nullptr;
+  MK_HIP(hipGetSymbolAddress(reinterpret_cast<void **>(&p), HIP_SYMBOL(scratch)));
+  if (!p) return fail(MK_ERR_HIP, "hipGetSymbolAddress returned no address for the static scratch");
+  g_scratch_ptr[device] = p;
+  return MK_OK;
+}
+
 __global__ void finish_dot_kernel(const double *slab, int nblocks, double *out2) {
   __shared__ double smem[2 * (kThreads / 64)];
   double v[2];
@@ -1697,6 +1724,39 @@ int mk_spmv_dot(const mk_matrix *A, const mk_vector *x, mk_vector *y, double *yt
   hipLaunchKernelGGL(finish_dot_kernel, dim3(1), dim3(kThreads), 0, c.stream, c.slab, nb, c.scalars);
   double h[2] = {0, 0};
   MK_HIP(hipMemcpyAsync(h, c.scalars, sizeof(h), hipMemcpyDeviceToHost, c.stream));
+  MK_HIP(hipStreamSynchronize(c.stream));
+  if (ytx) *ytx = h[0];
+  if (xtx) *xtx = h[1];
+  return MK_OK;
+}
+
+int mk_spmv_dot_static(const mk_matrix *A, const mk_vector *x, mk_vector *y, double *ytx, double *xtx) {
+  MK_REQUIRE_INIT();
+  if (!A || !x || !y) return fail(MK_ERR_INVALID, "mk_spmv_dot_static: null argument");
+  if (A->nrows != A->ncols) return fail(MK_ERR_INVALID, "mk_spmv_dot_static: matrix must be square");
+  if (x->n < A->ncols || y->n < A->nrows) return fail(MK_ERR_INVALID, "mk_spmv_dot_static: vector too short");
+  if (x->d == y->d) return fail(MK_ERR_INVALID, "mk_spmv_dot_static: x and y must not alias");
+  Context &c = ctx();
+  double *sp = (c.device >= 0 && c.device < kMaxDevices) ? g_scratch_ptr[c.device] : nullptr;
+  if (!sp) return fail(MK_ERR_NOT_INIT, "mk_spmv_dot_static: no static scratch address for device %d (mk_init sets it)", c.device);
+  // the analysis (row-length histogram, pattern tables, chunk starts) allocates: it must have run before
+  if (!A->analysed) return fail(MK_ERR_INVALID, "mk_spmv_dot_static: matrix not analysed yet; call mk_matrix_get_info (it allocates) first");
+  double *slab = sp, *out2 = sp + kStaticSlab, *carry = sp + kStaticSlab + 8;
+  int nb = 0;
+  if (A->kernel == MK_SPMV_SPLIT) {
+    if (!A->chunk_row) return fail(MK_ERR_INVALID, "mk_spmv_dot_static: the split kernel's chunk table is built (allocated) by the first mk_spmv / mk_spmv_dot; run one first");
+    if (A->nchunks > kStaticCarryChunks)
+      return fail(MK_ERR_UNSUPPORTED, "mk_spmv_dot_static: %lld entries in %d chunks exceed the static scratch (split-kernel matrices up to %lld entries)",
+                  (long long)A->nnz, A->nchunks, (long long)kStaticCarryChunks * kSplitChunk);
+    MK_TRY(launch_split<1>(A, 1.0, x->d, 0.0, y->d, slab, nullptr, &nb, carry, true));
+  } else {
+    MK_TRY(launch_spmv_dot(A, x->d, y->d, slab, nullptr, &nb));
+  }
+  if (nb > kSlabStride) return fail(MK_ERR_UNSUPPORTED, "mk_spmv_dot_static: %d reduction partials, the static scratch holds %d", nb, kSlabStride);
+  if (!ytx && !xtx) return MK_OK;
+  hipLaunchKernelGGL(finish_dot_kernel, dim3(1), dim3(kThreads), 0, c.stream, slab, nb, out2);
+  double *h = static_cast<double *>(c.pinned);   // pinned at mk_init: the copy needs no staging allocation
+  MK_HIP(hipMemcpyAsync(h, out2, 2 * sizeof(double), hipMemcpyDeviceToHost, c.stream));
   MK_HIP(hipStreamSynchronize(c.stream));
   if (ytx) *ytx = h[0];
   if (xtx) *xtx = h[1];
