@@ -124,9 +124,12 @@ typedef enum {
                               inside and across chunks, carries folded in a fixed order by a second small kernel */
   MK_SPMV_PATTERN = 4,     /* rows drawn from a small table of (offsets, values) patterns: one lane per row, 2 B of
                               matrix data per row; only when mk_matrix_info.value_patterns > 0 */
-  MK_SPMV_SWEEP = 5        /* pattern matrices whose rows are all sub-lists of ONE pattern with offsets a*P + b (grids):
+  MK_SPMV_SWEEP = 5,       /* pattern matrices whose rows are all sub-lists of ONE pattern with offsets a*P + b (grids):
                               a block sweeps plane by plane with the x window of three planes in LDS, so every x entry
                               is loaded once per block instead of once per neighbour */
+  MK_SPMV_VSWEEP = 6       /* the same sweep for grid operators with VARIABLE coefficients: column offsets from the pattern
+                              table (2 B per row instead of col[]), values streamed from val[] through LDS, x through the
+                              window ring; rows of at most 8 entries */
 } mk_spmv_kernel;
 /* override the selector (lanes_per_row: 0 = keep, else 1..64 power of two) */
 int mk_matrix_set_spmv_kernel(mk_matrix *A, int kernel, int lanes_per_row);

@@ -37,7 +37,7 @@ class MatrixInfo(C.Structure):
                 ("long_rows", C.c_int64), ("index_patterns", C.c_int64), ("value_patterns", C.c_int64)]
 
 
-SPMV_AUTO, SPMV_VECTOR, SPMV_STREAM, SPMV_SPLIT, SPMV_PATTERN, SPMV_SWEEP = 0, 1, 2, 3, 4, 5
+SPMV_AUTO, SPMV_VECTOR, SPMV_STREAM, SPMV_SPLIT, SPMV_PATTERN, SPMV_SWEEP, SPMV_VSWEEP = 0, 1, 2, 3, 4, 5, 6
 PRECOND_NONE, PRECOND_JACOBI = 0, 1
 
 # every symbol include/mk_krylov.h declares (tests check the library exports all of them)

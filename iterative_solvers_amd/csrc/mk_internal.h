@@ -140,6 +140,8 @@ struct mk_matrix {
   unsigned *pmask = nullptr;       // device, npat: which entries of the base pattern each pattern keeps
   mk::SweepEntry *etab = nullptr;  // device, 32 entries
   bool sweep_auto = false;         // enough parallelism for the sweep kernel to be the default
+  bool sweep_streamed = false;     // the plan matches column offsets only: values are streamed from val[] (spmv_vsweep_kernel)
+  mutable int vsweep_lds_set = 0;
   mutable int sweep_bpc[6] = {0, 0, 0, 0, 0, 0};
   mutable int sweep_lds_set[6] = {0, 0, 0, 0, 0, 0};   // dynamic LDS above 48 KB needs a one-time opt-in per kernel
   bool sweep_diag_uniform = false; // every row has the (single) diagonal entry of the base pattern
@@ -198,6 +200,11 @@ int launch_sweep_cg_pdots(const mk_matrix *A, const double *r, const double *p_o
 int sweep_uniform_diag(const mk_matrix *A, double *inv_diag);
 int launch_sweep_cg_resid_x(const mk_matrix *A, const double *p, double *r, double *x, const double *dinv, const double *slab_in,
                             int nblocks_in, int stride_in, double *slab_out, PcgState *st, int *nblocks);
+
+// sweep over grid matrices with per-row values (vsweep.hip); mode 0: y = alpha A x + beta y, 1: y = A x + partials of
+// <y,x>, <x,x>, 2: Jacobi sweep (as launch_jacobi_sweep)
+int launch_vsweep(const mk_matrix *A, int mode, double alpha, const double *x, double beta, double *y, double *slab, const int *done,
+                  int *nblocks, const double *rhs, const double *extra);
 
 int exclusive_scan_u32(const uint32_t *in, uint32_t *out, size_t n, uint32_t *total_out_dev);
 

@@ -185,13 +185,16 @@ constexpr int kSweepNS = 4;             // ring slots: planes k-1, k, k+1 and th
 constexpr int kSweepMaxSw = 2048;        // window entries per slab (LDS = 4 slabs x 8 B x this = 64 KB)
 
 // Can the sweep kernel serve this matrix?  tab/vals: the (offsets, values) pattern table.
-static int plan_sweep(mk_matrix *A, const std::vector<int> &tab, const std::vector<double> &vals) {
+// with_values = false: only the offsets come from the table, the values are streamed from val[] (spmv_vsweep_kernel,
+// vsweep.hip): patterns are matched on offsets alone and the chunk length is chosen so that the LDS stage of one
+// plane-step's values fits beside the window ring.
+static int plan_sweep(mk_matrix *A, const std::vector<int> &tab, const std::vector<double> &vals, bool with_values = true) {
   static const int off = getenv("MK_NO_SWEEP") ? atoi(getenv("MK_NO_SWEEP")) : 0;
   const int npat = A->npat, pml = A->pml;
   if (off || pml > 32 || (A->nrows + 8) * 8 >= (int64_t)1 << 32 || A->ncols * 8 >= (int64_t)1 << 32) return MK_OK;
   auto len_of = [&](int q) { return tab[(size_t)q * (pml + 1)]; };
   auto off_of = [&](int q, int k) { return tab[(size_t)q * (pml + 1) + 1 + k]; };
-  auto bits_of = [&](int q, int k) { unsigned long long u; memcpy(&u, &vals[(size_t)q * pml + k], 8); return u; };
+  auto bits_of = [&](int q, int k) { unsigned long long u = 0; if (with_values) memcpy(&u, &vals[(size_t)q * pml + k], 8); return u; };
   int base = 0;
   for (int q = 1; q < npat; q++) if (len_of(q) > len_of(base)) base = q;
   const int len = len_of(base);
@@ -214,7 +217,8 @@ static int plan_sweep(mk_matrix *A, const std::vector<int> &tab, const std::vect
   S.len = len;
   int maxabs = 0;
   for (int u = 0; u < len; u++) maxabs = std::max(maxabs, std::abs(off_of(base, u)));
-  const bool contiguous = (maxabs <= 768);
+  // streamed values leave less LDS for the window: offsets beyond 256 are taken as plane offsets there
+  const bool contiguous = (maxabs <= (with_values ? 768 : 256));
   if (contiguous) {   // banded: contiguous sweep, every offset is "near"; P = chunk size, set below
     for (int u = 0; u < len; u++) { ea[u] = 0; eb[u] = off_of(base, u); }
   } else {
@@ -242,7 +246,7 @@ static int plan_sweep(mk_matrix *A, const std::vector<int> &tab, const std::vect
   for (int u = 0; u < len; u++) {
     bmin = std::min(bmin, eb[u]);
     bmax = std::max(bmax, eb[u]);
-    ev[u] = vals[(size_t)base * pml + u];
+    ev[u] = with_values ? vals[(size_t)base * pml + u] : 0.0;
     if (off_of(base, u) == 0) { S.diag = u; S.dv = ev[u]; }
   }
   S.wlo = (-bmin + 1) & ~1;
@@ -255,8 +259,25 @@ static int plan_sweep(mk_matrix *A, const std::vector<int> &tab, const std::vect
   S.C = (env_c == 512 || env_c == 1024 || env_c == 2048) ? env_c : (halo >= 1200 ? 2048 : halo >= 512 ? 1024 : 512);
   if (S.C == 2048 && S.C + S.wlo + whi > 4096) S.C = 1024;
   if (S.C == 1024 && S.C + S.wlo + whi > kSweepMaxSw) S.C = 512;
+  if (!with_values) {
+    // values streamed: LDS = ring (4 slabs of C + halo entries) + one plane-step of values (len * C entries); chunks of
+    // 512 rows run two blocks per CU, chunks of 1024 one.  MK_VSWEEP_C picks for A/B runs.
+    static const int env_vc = getenv("MK_VSWEEP_C") ? atoi(getenv("MK_VSWEEP_C")) : 0;
+    auto fits = [&](int C) {
+      const int sw = C + halo;
+      const size_t lds = (size_t)kSweepNS * sw * 8 + ((size_t)len * C + 8) * 8 + (size_t)npat * 4;
+      return len <= 8 && lds <= 158 * 1024 && sw <= (C == 512 ? 1536 : 3072);
+    };
+    // measured (7-pt, product + dots): 512^3 C = 1024 1.955 ms / C = 512 2.05 ms; 256^3 (64 chunks of 1024 per plane)
+    // 0.260 / 0.249 ms: the long chunk (window 2x instead of 3x the chunk) wins once a plane fills the chip with them
+    if ((env_vc == 512 || env_vc == 1024) && fits(env_vc)) S.C = env_vc;
+    else if (fits(1024) && S.P / 1024 >= ctx().num_cus && halo >= 512) S.C = 1024;
+    else if (fits(512)) S.C = 512;
+    else if (fits(1024)) S.C = 1024;
+    else return MK_OK;
+  }
   S.sw = S.C + S.wlo + whi;
-  if (S.sw > (S.C == 2048 ? 4096 : kSweepMaxSw)) return MK_OK;
+  if (with_values && S.sw > (S.C == 2048 ? 4096 : kSweepMaxSw)) return MK_OK;   // (streamed: fits() has checked)
   if (contiguous) S.P = S.C;
   S.K = (int)((A->nrows + S.P - 1) / S.P);
   S.ncp = (S.P + S.C - 1) / S.C;
@@ -274,6 +295,7 @@ static int plan_sweep(mk_matrix *A, const std::vector<int> &tab, const std::vect
   MK_HIP(hipMemcpyAsync(A->etab, E, sizeof(E), hipMemcpyHostToDevice, ctx().stream));
   MK_HIP(hipStreamSynchronize(ctx().stream));
   A->sweep = new SweepArgs(S);
+  A->sweep_streamed = !with_values;
   // one diagonal entry in the base pattern and every row keeps it: 1/diag is one number (fused Jacobi-PCG step)
   int ndiag = 0;
   for (int u = 0; u < len; u++) ndiag += (off_of(base, u) == 0);
@@ -356,6 +378,8 @@ static int try_compress(mk_matrix *A) {
         MK_HIP(hipStreamSynchronize(c.stream));
         A->p8 = P8;
         MK_TRY(plan_sweep(A, tab, vals));
+      } else {
+        MK_TRY(plan_sweep(A, tab, std::vector<double>(), false));   // offsets from the table, values streamed
       }
     }
   }
@@ -410,6 +434,8 @@ int analyse_matrix(mk_matrix *A) {
     MK_TRY(try_compress<true>(A));                 // offsets and values shared by rows -> pattern kernel
     if (!A->pat) MK_TRY(try_compress<false>(A));   // offsets only -> stream kernel without col[]
     if (A->vtab && was_auto) A->kernel = (A->sweep && A->sweep_auto) ? MK_SPMV_SWEEP : MK_SPMV_PATTERN;
+    static const int no_vsweep = getenv("MK_NO_VSWEEP") ? atoi(getenv("MK_NO_VSWEEP")) : 0;
+    if (!A->vtab && A->pat && A->sweep && A->sweep_streamed && A->sweep_auto && was_auto && !no_vsweep) A->kernel = MK_SPMV_VSWEEP;
   }
   I.kernel = A->kernel;
   I.index_patterns = A->pat ? A->npat : 0;
@@ -1344,7 +1370,7 @@ static int launch_sweep(const mk_matrix *A, double alpha, const double *x, doubl
                         PcgState *st = nullptr, const double *slab_in = nullptr, int nblocks_in = 0, int stride_in = kSlabStride,
                         double *xupd = nullptr, int flags = 0, double *norms = nullptr) {
   Context &c = ctx();
-  if (!A->sweep) return fail(MK_ERR_UNSUPPORTED, "spmv: the sweep kernel needs rows that are sub-lists of one pattern with offsets a*P + b");
+  if (!A->sweep || A->sweep_streamed) return fail(MK_ERR_UNSUPPORTED, "spmv: the sweep kernel needs rows that are sub-lists of one (offsets, values) pattern with offsets a*P + b");
   SweepArgs S = *A->sweep;
   const size_t lds = (size_t)kSweepNS * S.sw * 8 + (size_t)A->npat * 4;
   static const int env_bpc = getenv("MK_SWEEP_BPC") ? atoi(getenv("MK_SWEEP_BPC")) : 0;
@@ -1613,6 +1639,7 @@ static int launch_split(const mk_matrix *A, double alpha, const double *x, doubl
 int launch_spmv(const mk_matrix *A, double alpha, const double *x, double beta, double *y, const int *skip) {
   MK_TRY(analyse_matrix(const_cast<mk_matrix *>(A)));
   if (A->nrows == 0) return MK_OK;
+  if (A->kernel == MK_SPMV_VSWEEP) return launch_vsweep(A, 0, alpha, x, beta, y, nullptr, skip, nullptr, nullptr, nullptr);
   if (A->kernel == MK_SPMV_SWEEP) return launch_sweep<0>(A, alpha, x, beta, y, nullptr, skip, nullptr);
   if (A->kernel == MK_SPMV_PATTERN) return launch_pattern<0>(A, alpha, x, beta, y, nullptr, skip, nullptr);
   if (A->kernel == MK_SPMV_STREAM) return launch_stream<0>(A, alpha, x, beta, y, nullptr, skip, nullptr);
@@ -1625,6 +1652,7 @@ int launch_spmv(const mk_matrix *A, double alpha, const double *x, double beta, 
 int launch_jacobi_sweep(const mk_matrix *A, const double *rhs, const double *extra, const double *xold, double *xnew,
                         double *slab, const int *done, int *nblocks) {
   MK_TRY(analyse_matrix(const_cast<mk_matrix *>(A)));
+  if (A->kernel == MK_SPMV_VSWEEP) return launch_vsweep(A, 2, 1.0, xold, 0.0, xnew, slab, done, nblocks, rhs, extra);
   if (A->kernel == MK_SPMV_SWEEP) return launch_sweep<2>(A, 1.0, xold, 0.0, xnew, slab, done, nblocks, rhs, extra);
   if (A->kernel == MK_SPMV_PATTERN) return launch_pattern<2>(A, 1.0, xold, 0.0, xnew, slab, done, nblocks, rhs, extra);
   if (A->kernel != MK_SPMV_STREAM) return MK_ERR_UNSUPPORTED;
@@ -1636,7 +1664,7 @@ int launch_sweep_cg_dots(const mk_matrix *A, const double *p, double *slab_out, 
 }
 
 int sweep_uniform_diag(const mk_matrix *A, double *inv_diag) {
-  if (!A->sweep || !A->sweep_diag_uniform) return 0;
+  if (!A->sweep || !A->sweep_diag_uniform || A->sweep_streamed) return 0;
   if (inv_diag) *inv_diag = 1.0 / A->sweep->dv;
   return 1;
 }
@@ -1657,6 +1685,7 @@ int launch_sweep_cg_resid_x(const mk_matrix *A, const double *p, double *r, doub
 
 int launch_spmv_dot(const mk_matrix *A, const double *x, double *y, double *slab, const int *done, int *nblocks) {
   MK_TRY(analyse_matrix(const_cast<mk_matrix *>(A)));
+  if (A->kernel == MK_SPMV_VSWEEP) return launch_vsweep(A, 1, 1.0, x, 0.0, y, slab, done, nblocks, nullptr, nullptr);
   if (A->kernel == MK_SPMV_SWEEP) return launch_sweep<1>(A, 1.0, x, 0.0, y, slab, done, nblocks);
   if (A->kernel == MK_SPMV_PATTERN) return launch_pattern<1>(A, 1.0, x, 0.0, y, slab, done, nblocks);
   if (A->kernel == MK_SPMV_STREAM) return launch_stream<1>(A, 1.0, x, 0.0, y, slab, done, nblocks);
@@ -1776,10 +1805,13 @@ int mk_matrix_set_spmv_kernel(mk_matrix *A, int kernel, int lanes_per_row) {
   if (!A) return fail(MK_ERR_INVALID, "mk_matrix_set_spmv_kernel: null matrix");
   MK_TRY(analyse_matrix(A));
   if (kernel != MK_SPMV_AUTO && kernel != MK_SPMV_VECTOR && kernel != MK_SPMV_STREAM && kernel != MK_SPMV_SPLIT &&
-      kernel != MK_SPMV_PATTERN && kernel != MK_SPMV_SWEEP)
+      kernel != MK_SPMV_PATTERN && kernel != MK_SPMV_SWEEP && kernel != MK_SPMV_VSWEEP)
     return fail(MK_ERR_INVALID, "mk_matrix_set_spmv_kernel: unknown kernel %d", kernel);
-  if (kernel == MK_SPMV_SWEEP && !A->sweep)
-    return fail(MK_ERR_UNSUPPORTED, "mk_matrix_set_spmv_kernel: the rows of this matrix are not sub-lists of one grid pattern");
+  if (kernel == MK_SPMV_SWEEP && (!A->sweep || A->sweep_streamed))
+    return fail(MK_ERR_UNSUPPORTED, "mk_matrix_set_spmv_kernel: the rows of this matrix are not sub-lists of one grid pattern with shared values");
+  if (kernel == MK_SPMV_VSWEEP && (!A->sweep || !A->sweep_streamed))
+    return fail(MK_ERR_UNSUPPORTED, "mk_matrix_set_spmv_kernel: MK_SPMV_VSWEEP serves matrices whose rows are sub-lists (by column offset) of one grid "
+                                    "pattern of at most 8 entries and do not share their values (constant coefficients: MK_SPMV_SWEEP)");
   if (kernel == MK_SPMV_PATTERN && !A->vtab)
     return fail(MK_ERR_UNSUPPORTED, "mk_matrix_set_spmv_kernel: the rows of this matrix do not share (offsets, values) patterns");
   if (lanes_per_row != 0) {

@@ -1,0 +1,338 @@
+// vsweep.hip -- plane sweep for grid operators with VARIABLE coefficients (MK_SPMV_VSWEEP).
+//
+// Stands in for hypre_ParCSRMatrixMatvec on matrices like the authors' real inputs: a grid structure, every row its own
+// values.  The constant-coefficient sweep (spmv.hip spmv_sweep_kernel) reads no CSR array at all; here the values are
+// what the product is bound by (8 B per entry), and everything else is arranged so that nothing but them, one 2-byte
+// pattern id, one 4-byte row pointer, x once and y once crosses the HBM interface per row:
+//   - x: block (chunk of C = 2T rows of a plane, z-segment) walks plane by plane, the x entries of planes k-1, k, k+1
+//     around its rows sit in an LDS ring of four slabs filled by coalesced 16-byte loads that run three planes ahead in
+//     registers (as in spmv_sweep_kernel): every gather is an LDS read, HBM sees x once;
+//   - values: the rows of a chunk are consecutive, so their values are ONE contiguous span val[rowptr[g0] ..
+//     rowptr[g0 + C]): it is loaded with coalesced 16-byte loads three steps ahead, staged in LDS, and every row reads
+//     its entries from there at rowptr[row] - rowptr[g0] + (number of earlier entries of the base pattern the row has);
+//   - column indices: never read.  Row r's pattern id selects a bit mask over the base pattern (offsets a*P + b), whose
+//     LDS ring offsets come eight at a time from a table by scalar loads.
+// Rows are summed left to right over the same (value, x) pairs as the CSR arrays hold, so the result equals the serial
+// reference's bit for bit (same rounding sequence).  Algorithmic bytes: SURVEY 8(d)'s 12 nnz + 20 n + 4; read here:
+// 8 nnz + 22 n.
+#include "mk_internal.h"
+
+namespace mk {
+
+typedef double d2_t __attribute__((ext_vector_type(2)));
+typedef double d2u_t __attribute__((ext_vector_type(2), aligned(8)));   // 16-byte access that is only 8-byte aligned
+typedef int i2_t __attribute__((ext_vector_type(2)));
+constexpr int kNS = 4;   // ring slots: planes k-1, k, k+1 and the one being written
+
+template <bool NT, typename V>
+__device__ __forceinline__ void vs_st(V *ptr, V v) {
+  if (NT) __builtin_nontemporal_store(v, ptr); else *ptr = v;
+}
+template <bool NT, typename V>
+__device__ __forceinline__ V vs_ld(const V *ptr) {
+  return NT ? __builtin_nontemporal_load(ptr) : *ptr;
+}
+
+template <bool NT>
+__device__ __forceinline__ d2u_t vs_ld_u(const d2u_t *ptr) {   // keeps the 8-byte alignment of the type (no template deduction on it)
+  if (NT) return __builtin_nontemporal_load(ptr);
+  return *ptr;
+}
+
+// MODE 0: y = alpha A x + beta y.  1: y = A x, partials of <y,x>, <x,x>.  2: Jacobi sweep y = x + D^-1 (rhs - extra - A x),
+// partial of ||rhs - extra - A x||^2, D picked up from the row's own entry with offset 0 (the last one stored).
+// NL = 16-byte ring loads per thread per slab = ceil(sw / 2T); NVL = 16-byte value loads per thread per plane-step
+// (NVL * 2T >= len * C entries).
+template <int MODE, int NL, int NVL, int T, bool NT>
+__global__ __launch_bounds__(T, 2) void spmv_vsweep_kernel(
+    const SweepArgs S, const SweepEntry *__restrict__ etab, int64_t nrows, int64_t ncols, int64_t nnz,
+    const unsigned short *__restrict__ pat, const unsigned *__restrict__ pmask, int npat, const int *__restrict__ rowptr,
+    const double *__restrict__ val, const double *__restrict__ x, double *__restrict__ y, double alpha, double beta,
+    double *__restrict__ slab, const int *__restrict__ done, const double *__restrict__ rhs, const double *__restrict__ extra) {
+  if (done != nullptr && *done != 0) return;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  constexpr int C = 2 * T, NS = kNS, VCAP = NVL * 2 * T;
+  const int sw = S.sw;
+  double *ring = reinterpret_cast<double *>(smem_raw);          // NS slabs of sw entries
+  double *sval = ring + NS * sw;                                 // VCAP + 8 entries: the values of one plane-step
+  unsigned *smask = reinterpret_cast<unsigned *>(sval + VCAP + 8);   // npat
+  const int tid = threadIdx.x;
+  for (int i = tid; i < npat; i += T) smask[i] = pmask[i];
+  const int nb = gridDim.x;   // multiple of 8; blocks of one XCD take neighbouring chunks of a plane (shared halos in its L2)
+  const int lid = (blockIdx.x & 7) * (nb >> 3) + (blockIdx.x >> 3);
+  double acc0 = 0.0, acc1 = 0.0;
+  if (lid < S.ncp * S.nseg) {
+    const int nr = (int)nrows;
+    const int cp = lid % S.ncp, seg = lid / S.ncp;
+    const int k0 = (int)((int64_t)seg * S.K / S.nseg), k1 = (int)((int64_t)(seg + 1) * S.K / S.nseg);
+    const int r0 = cp * C;
+    const int rows_here = min(C, S.P - r0);
+    const int lr = 2 * tid;
+    // every load that runs ahead is unconditional, with its address clamped into the arrays (see spmv_sweep_kernel)
+    const int xlast = ((int)ncols - 1) & ~1;
+    const int rlast = (nr - 1) & ~1;
+    const int elast = (int)max((int64_t)0, nnz - 1);   // val[elast + 1] is allocation slack (dev_alloc): never used by a row
+
+    auto load_slab = [&](int j, d2_t(&reg)[NL]) {   // window of plane j
+      const int g0 = min(j, k1) * S.P + r0 - S.wlo + lr;
+#pragma unroll
+      for (int i = 0; i < NL; i++) {
+        const int g = min(max(g0 + i * 2 * T, 0), xlast);
+        reg[i] = *reinterpret_cast<const d2_t *>(reinterpret_cast<const char *>(x) + ((unsigned)g << 3));
+      }
+    };
+    auto write_slab = [&](int slot, const d2_t(&reg)[NL]) {
+      double *dst = ring + slot * sw + lr;
+#pragma unroll
+      for (int i = 0; i < NL; i++)
+        if (lr + i * 2 * T < sw) *reinterpret_cast<d2_t *>(dst + i * 2 * T) = reg[i];
+    };
+    // first value of the chunk's rows in plane j (uniform over the block: scalar loads)
+    auto span_begin = [&](int j) -> int { return rowptr[min(min(j, k1) * S.P + r0, nr)]; };
+    auto load_vals = [&](int vb, d2u_t(&reg)[NVL]) {   // val[vb + 2 (tid + i T)], two at a time
+#pragma unroll
+      for (int i = 0; i < NVL; i++) {
+        const int e = min(vb + 2 * (tid + i * T), elast);
+        reg[i] = vs_ld_u<NT>(reinterpret_cast<const d2u_t *>(reinterpret_cast<const char *>(val) + ((size_t)(unsigned)e << 3)));
+      }
+    };
+    // LDS stage of the values, swizzled: entry e lives at e ^ ((e >> 5) & 1).  A lane reads the values of its two
+    // rows at a stride of 2 * len entries from its neighbour's: an even stride uses only every other pair of banks and
+    // 64-bit reads collide two ways (measured: bank-conflict cycles were 70 % of the LDS busy cycles); flipping the low
+    // bit in every other block of 32 entries makes the 32 lanes of a pass hit 32 different bank pairs for len 3, 5, 7.
+    // A thread's write positions 2 (tid + i T) all have bit 5 = bit 4 of tid: it swaps its pairs or never does.
+    const bool swp = (tid >> 4) & 1;
+    auto write_vals = [&](const d2u_t(&reg)[NVL]) {
+#pragma unroll
+      for (int i = 0; i < NVL; i++) {
+        d2_t v;
+        v.x = swp ? reg[i].y : reg[i].x;
+        v.y = swp ? reg[i].x : reg[i].y;
+        *reinterpret_cast<d2_t *>(sval + 2 * (tid + i * T)) = v;
+      }
+    };
+    auto stage_at = [&](int idx) -> double { return sval[idx ^ ((idx >> 5) & 1)]; };
+    auto row_of = [&](int j) -> int { return j * S.P + r0 + lr; };
+    auto live = [&](int j) -> bool { return j < k1 && lr < rows_here && row_of(j) < nr; };
+    auto load_ids = [&](int j) -> unsigned {   // pattern ids of rows g, g+1 (g even); the id behind the last row is slack
+      const int g = min(row_of(j), rlast);
+      return vs_ld<NT>(reinterpret_cast<const unsigned *>(reinterpret_cast<const char *>(pat) + ((unsigned)g << 1)));
+    };
+    auto load_rp = [&](int j) -> i2_t {        // rowptr[g], rowptr[g+1]; rowptr has nrows + 1 entries and slack behind
+      const int g = min(row_of(j), rlast);
+      return vs_ld<NT>(reinterpret_cast<const i2_t *>(reinterpret_cast<const char *>(rowptr) + ((unsigned)g << 2)));
+    };
+    auto load_pair = [&](const double *p, int j) -> d2_t {
+      const int g = min(row_of(j), rlast);
+      return vs_ld<NT>(reinterpret_cast<const d2_t *>(reinterpret_cast<const char *>(p) + ((unsigned)g << 3)));
+    };
+    const double *aux = (MODE == 2) ? rhs : (MODE == 0 && beta != 0.0) ? y : nullptr;
+    constexpr bool kExtra = (MODE == 2);
+
+    // register stages, used in place: ring stage (k mod 3) holds slab k+2 at step k; value stage ((k+1) mod 3) holds the
+    // values of plane k+1 at step k, is written to LDS behind the step's first barrier and re-loaded with plane k+4
+    d2_t st0[NL], st1[NL], st2[NL];
+    d2u_t vs0[NVL], vs1[NVL], vs2[NVL];
+    int vb0 = span_begin(k0), vb1 = span_begin(k0 + 1), vb2 = span_begin(k0 + 2);
+    load_slab(k0 - 1, st0);
+    load_slab(k0, st1);
+    load_slab(k0 + 1, st2);
+    load_vals(vb0, vs0);
+    write_slab(0, st0);
+    write_slab(1, st1);
+    write_slab(2, st2);
+    write_vals(vs0);
+    int vbcur = vb0;                // span begin of the plane whose values sit in LDS
+    load_vals(vb1, vs1);
+    load_vals(vb2, vs2);
+    vb0 = span_begin(k0 + 3);
+    load_vals(vb0, vs0);
+    int vbn = span_begin(k0 + 4);   // begin of the span loaded next (plane k+4 at step k), fetched one step early
+    d2_t ax0 = {0.0, 0.0}, ax1 = ax0, ax2 = ax0, ex0 = ax0, ex1 = ax0, ex2 = ax0;
+    unsigned id0 = load_ids(k0);
+    i2_t rp0 = load_rp(k0);
+    if (aux) ax0 = load_pair(aux, k0);
+    if (kExtra && extra) ex0 = load_pair(extra, k0);
+    load_slab(k0 + 2, st0);
+    unsigned id1 = load_ids(k0 + 1);
+    i2_t rp1 = load_rp(k0 + 1);
+    if (aux) ax1 = load_pair(aux, k0 + 1);
+    if (kExtra && extra) ex1 = load_pair(extra, k0 + 1);
+    load_slab(k0 + 3, st1);
+    unsigned id2 = load_ids(k0 + 2);
+    i2_t rp2 = load_rp(k0 + 2);
+    if (aux) ax2 = load_pair(aux, k0 + 2);
+    if (kExtra && extra) ex2 = load_pair(extra, k0 + 2);
+    load_slab(k0 + 4, st2);
+    __syncthreads();
+
+    // vbcur: span begin of plane k (its values are in sval now).  vsn / vbs: value stage of plane k+1 and its span begin,
+    // re-loaded with plane k+4 whose span begin is vbn (fetched during the previous step).
+    auto step = [&](int k, d2_t(&st)[NL], unsigned &idr, i2_t &rpr, d2_t &axr, d2_t &exr, d2u_t(&vsn)[NVL], int &vbs) {
+      const int vbk = vbcur;
+      const unsigned idc = idr;
+      const i2_t rpc = rpr;
+      const d2_t axc = axr, exc = exr;
+      const int jb = (k - k0 + 1) & (NS - 1);   // ring slot of plane k
+      if (live(k)) {
+        const int g = row_of(k);
+        const bool two = g + 1 < nr;
+        const unsigned mA = smask[idc & 0xffffu];
+        const unsigned mB = two ? smask[min(idc >> 16, (unsigned)npat - 1u)] : 0u;
+        const char *wl = reinterpret_cast<const char *>(ring) + lr * 8;
+        // positions of the two rows' first values in the stage; a row without a live partner reads its own
+        const int vA = rpc.x - vbk;
+        const int vB = two ? rpc.y - vbk : vA;
+        double s0 = 0.0, s1 = 0.0;
+        for (int u0 = 0; u0 < S.len; u0 += 8) {
+          typedef int i16_t __attribute__((ext_vector_type(16)));
+          const i16_t *eb = reinterpret_cast<const i16_t *>(etab + jb * 32 + u0);
+          const i16_t b0 = eb[0], b1 = eb[1];
+          const int off[8] = {b0[0], b0[4], b0[8], b0[12], b1[0], b1[4], b1[8], b1[12]};
+          const unsigned ka = mA >> u0, kb = mB >> u0;
+          const int va0 = vA + __popc(mA & ((1u << u0) - 1u));
+          const int vb0p = vB + __popc(mB & ((1u << u0) - 1u));
+          double p0[8], p1[8], c0[8], c1[8];
+#pragma unroll
+          for (int u = 0; u < 8; u++) {
+            const double *w = reinterpret_cast<const double *>(wl + off[u]);
+            p0[u] = w[0];
+            p1[u] = w[1];
+            // the u-th entry of the base pattern is the row's (number of earlier entries it has)-th value
+            c0[u] = stage_at(va0 + __popc(ka & ((1u << u) - 1u)));
+            c1[u] = stage_at(vb0p + __popc(kb & ((1u << u) - 1u)));
+          }
+#pragma unroll
+          for (int u = 0; u < 8; u++) {
+            const double t0 = s0 + c0[u] * p0[u], t1 = s1 + c1[u] * p1[u];
+            s0 = ((ka >> u) & 1u) ? t0 : s0;
+            s1 = ((kb >> u) & 1u) ? t1 : s1;
+          }
+        }
+        d2_t out;
+        if (MODE == 0) {
+          out.x = (beta == 0.0) ? alpha * s0 : alpha * s0 + beta * axc.x;
+          out.y = (beta == 0.0) ? alpha * s1 : alpha * s1 + beta * axc.y;
+        } else {
+          const double *wc = reinterpret_cast<const double *>(wl) + jb * sw + S.wlo;   // x[g], x[g+1]
+          const double xa = wc[0], xb = wc[1];
+          if (MODE == 2) {
+            const double ra = (axc.x - exc.x) - s0, rb = (axc.y - exc.y) - s1;
+            double da = 0.0, db = 0.0;
+            if (S.diag >= 0) {
+              const unsigned below = (1u << S.diag) - 1u;
+              if ((mA >> S.diag) & 1u) da = stage_at(vA + __popc(mA & below));
+              if ((mB >> S.diag) & 1u) db = stage_at(vB + __popc(mB & below));
+            }
+            out.x = xa + ra / da;
+            out.y = xb + rb / db;
+            acc0 += ra * ra;
+            if (two) acc0 += rb * rb;
+          } else {
+            out.x = s0;
+            out.y = s1;
+            acc0 += s0 * xa;
+            acc1 += xa * xa;
+            if (two) { acc0 += s1 * xb; acc1 += xb * xb; }
+          }
+        }
+        if (two) vs_st<NT>(reinterpret_cast<d2_t *>(reinterpret_cast<char *>(y) + ((unsigned)g << 3)), out);
+        else *reinterpret_cast<double *>(reinterpret_cast<char *>(y) + ((unsigned)g << 3)) = out.x;
+      }
+      __syncthreads();   // everybody has read this plane's values
+      // slab k+2 (loaded three steps ago) into the slot plane k-2 occupied; the values of plane k+1 into the stage
+      write_slab((k - k0 + 3) & (NS - 1), st);
+      write_vals(vsn);
+      // look-ahead loads into the registers just consumed: ids / row pointers / aux of plane k+3, slab k+5, values k+4
+      idr = load_ids(k + 3);
+      rpr = load_rp(k + 3);
+      if (aux) axr = load_pair(aux, k + 3);
+      if (kExtra && extra) exr = load_pair(extra, k + 3);
+      load_slab(k + 5, st);
+      vbcur = vbs;
+      vbs = vbn;
+      load_vals(vbn, vsn);
+      vbn = span_begin(k + 5);
+      __syncthreads();
+    };
+    for (int k = k0; k < k1; k += 3) {   // straight-line body: steps at or behind k1 compute nothing (live() is false)
+      step(k, st0, id0, rp0, ax0, ex0, vs1, vb1);
+      step(k + 1, st1, id1, rp1, ax1, ex1, vs2, vb2);
+      step(k + 2, st2, id2, rp2, ax2, ex2, vs0, vb0);
+    }
+  }
+  if (MODE != 0) {
+    __syncthreads();
+    double w[2] = {acc0, acc1};
+    block_sum<2, T>(w, ring);
+    if (threadIdx.x == 0) {
+      slab[0 * kSlabStride + blockIdx.x] = w[0];
+      if (MODE == 1) slab[1 * kSlabStride + blockIdx.x] = w[1];
+    }
+  }
+}
+
+template <int MODE, int NL, int NVL, int T>
+static int launch_vsweep_t(const mk_matrix *A, const SweepArgs &S, size_t lds, int blocks, bool nt, double alpha, const double *x, double beta,
+                           double *y, double *slab, const int *done, const double *rhs, const double *extra) {
+  Context &c = ctx();
+  auto kern = nt ? spmv_vsweep_kernel<MODE, NL, NVL, T, true> : spmv_vsweep_kernel<MODE, NL, NVL, T, false>;
+  if (lds > 48 * 1024)   // dynamic LDS above 48 KB needs an opt-in per kernel (cheap, no allocation)
+    MK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(T), lds, c.stream, S, A->etab, A->nrows, A->ncols, A->nnz, A->pat, A->pmask,
+                     A->npat, A->rowptr, A->val, x, y, alpha, beta, slab, done, rhs, extra);
+  MK_HIP(hipGetLastError());
+  return MK_OK;
+}
+
+template <int MODE>
+static int launch_vsweep_m(const mk_matrix *A, double alpha, const double *x, double beta, double *y, double *slab, const int *done,
+                           int *nblocks, const double *rhs, const double *extra) {
+  Context &c = ctx();
+  if (!A->sweep || !A->sweep_streamed || !A->pat)
+    return fail(MK_ERR_UNSUPPORTED, "spmv: MK_SPMV_VSWEEP needs rows that are sub-lists, by column offset, of one grid pattern of at most 8 entries");
+  SweepArgs S = *A->sweep;
+  const int T = S.C / 2;
+  const int nvl = S.len <= 3 ? 3 : S.len <= 5 ? 5 : S.len <= 7 ? 7 : 8;
+  const size_t lds = (size_t)kNS * S.sw * 8 + ((size_t)nvl * S.C + 8) * 8 + (size_t)A->npat * 4;
+  if (S.len > 8 || lds > 160 * 1024) return fail(MK_ERR_UNSUPPORTED, "spmv: vsweep stage of %zu bytes does not fit the LDS", lds);
+  const int per_cu = std::max(1, (int)((160 * 1024) / lds));
+  // segments: two rounds of resident blocks (each segment re-reads two halo planes: at least 8 planes per segment)
+  static const int env_nseg = getenv("MK_SWEEP_NSEG") ? atoi(getenv("MK_SWEEP_NSEG")) : 0;
+  const int64_t target = (int64_t)c.num_cus * per_cu;
+  int nseg = env_nseg > 0 ? env_nseg : (int)std::max<int64_t>(1, (2 * target + S.ncp - 1) / S.ncp);
+  nseg = std::min(nseg, std::max(1, S.K / 8));
+  nseg = std::max(1, std::min(nseg, S.K));
+  while ((int64_t)S.ncp * nseg > kSlabStride - 8 && nseg > 1) nseg--;
+  if ((int64_t)S.ncp * nseg > kSlabStride - 8) return fail(MK_ERR_UNSUPPORTED, "spmv: sweep grid of %d chunks per plane is too large", S.ncp);
+  S.nseg = nseg;
+  const int blocks = (S.ncp * nseg + 7) / 8 * 8;
+  if (nblocks) *nblocks = blocks;
+  const int nl = std::max(2, (S.sw + 2 * T - 1) / (2 * T));
+  const bool nt = nt_rows(A->nrows) || nt_matrix((double)A->nnz * 8.0);
+#define MK_VS(NLL, NVV, TT) return launch_vsweep_t<MODE, NLL, NVV, TT>(A, S, lds, blocks, nt, alpha, x, beta, y, slab, done, rhs, extra);
+#define MK_VS_NV(NLL, TT)                \
+  switch (nvl) {                         \
+    case 3: MK_VS(NLL, 3, TT)            \
+    case 5: MK_VS(NLL, 5, TT)            \
+    case 7: MK_VS(NLL, 7, TT)            \
+    default: MK_VS(NLL, 8, TT)           \
+  }
+  if (T == 256 && nl == 2) { MK_VS_NV(2, 256) }
+  if (T == 256 && nl == 3) { MK_VS_NV(3, 256) }
+  if (T == 512 && nl == 2) { MK_VS_NV(2, 512) }
+  if (T == 512 && nl == 3) { MK_VS_NV(3, 512) }
+#undef MK_VS_NV
+#undef MK_VS
+  return fail(MK_ERR_UNSUPPORTED, "spmv: vsweep window of %d entries for chunks of %d rows", S.sw, S.C);
+}
+
+int launch_vsweep(const mk_matrix *A, int mode, double alpha, const double *x, double beta, double *y, double *slab, const int *done,
+                  int *nblocks, const double *rhs, const double *extra) {
+  if (mode == 0) return launch_vsweep_m<0>(A, alpha, x, beta, y, slab, done, nblocks, rhs, extra);
+  if (mode == 1) return launch_vsweep_m<1>(A, alpha, x, beta, y, slab, done, nblocks, rhs, extra);
+  if (mode == 2) return launch_vsweep_m<2>(A, alpha, x, beta, y, slab, done, nblocks, rhs, extra);
+  return fail(MK_ERR_INVALID, "launch_vsweep: mode %d", mode);
+}
+
+}  // namespace mk

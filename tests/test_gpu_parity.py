@@ -338,6 +338,138 @@ def test_spmv_sweep_kernel_random_patterns(seed, P, K, nbase):
         assert np.allclose(xj.get(), oj["x"], rtol=1e-12, atol=0), k
 
 
+def _vsweep_checks(A, rp, ci, v, n, rng, jacobi=True):
+    """MK_SPMV_VSWEEP against the serial reference: product, product + dots, alpha/beta forms, Jacobi sweeps"""
+    A.set_spmv_kernel(mk.SPMV_VSWEEP)
+    assert A.info().kernel == mk.SPMV_VSWEEP and A.info().value_patterns == 0 and A.info().index_patterns > 0
+    xh = rng.normal(size=n)
+    ref = oracle.csr_spmv(rp, ci, v, xh)
+    x, y = mk.Vector(n, values=xh), mk.Vector(n, fill=7.0)
+    A.spmv(x, y)
+    assert np.array_equal(y.get(), ref)                    # same (value, x) pairs in the same order: the reference's bits
+    y.fill(-1.0)
+    yx, xx = A.spmv_dot(x, y)
+    assert np.array_equal(y.get(), ref)
+    assert abs(yx - ref @ xh) <= 1e-12 * np.abs(ref * xh).sum() and abs(xx - xh @ xh) <= 1e-12 * (xh @ xh)
+    _check_spmv(A, rp, ci, v, n, n, rng, alpha=-1.0, beta=1.0)
+    _check_spmv(A, rp, ci, v, n, n, rng, alpha=0.5, beta=-2.0)
+    if jacobi:
+        oj = oracle.jacobi(rp, ci, v, np.ones(n), tol=1e-30, maxit=9, check_every=4)
+        J = mk.Jacobi(max_iter=9, tol=1e-30, check_every=4)
+        b, xj = mk.Vector(n, fill=1.0), mk.Vector(n, fill=0.0)
+        J.setup(A, b, xj)
+        J.solve(A, b, xj)
+        assert np.allclose(xj.get(), oj["x"], rtol=1e-12, atol=0)
+
+
+@pytest.mark.parametrize("kind,dims", [(7, (64, 64, 40)), (7, (30, 22, 10)), (5, (128, 96, 1)), (7, (512, 4, 5)), (7, (24, 16, 33)),
+                                       (7, (640, 4, 5)), (7, (1024, 3, 9)), (5, (1000, 700, 1)), (7, (6, 6, 100))])
+def test_spmv_vsweep_kernel_variable_coefficients(kind, dims):
+    """grid operators with per-row coefficients (D A D): column offsets from the pattern table, values streamed through LDS,
+    x through the window ring (vsweep.hip)"""
+    rng = np.random.default_rng(kind + 300)
+    rp, ci, v = oracle.stencil_csr(kind, *dims, scale_seed=11)
+    n = rp.size - 1
+    A = mk.Matrix.from_csr(n, n, rp, ci, v)
+    _vsweep_checks(A, rp, ci, v, n, rng)
+    # a whole CG solve through it (K1 on the vsweep kernel, K2/K3 the vector kernels) against the oracle
+    bh = rng.normal(size=n)
+    o = oracle.pcg(rp, ci, v, bh, tol=1e-9, precond=1, maxit=400, want_norms=True)     # the large 2D grid stops at 400 unconverged
+    b, x0 = mk.Vector(n, values=bh), mk.Vector(n, fill=0.0)
+    S = mk.PCG(max_iter=400, tol=1e-9, precond=mk.PRECOND_JACOBI, logging=1)
+    S.setup(A, b, x0)
+    r = S.solve(A, b, x0)
+    assert r["converged"] == o["converged"] and abs(r["iterations"] - o["iterations"]) <= CG_ITER_TOL
+    assert np.linalg.norm(x0.get() - o["x"]) <= 1e-6 * np.linalg.norm(o["x"])
+    hist = S.residual_history(4000)
+    m = min(hist.size, o["rel_norms"].size, 30)
+    assert np.allclose(hist[:m], o["rel_norms"][:m], rtol=1e-8)
+
+
+def test_spmv_vsweep_device_generated_matches_oracle_generator():
+    """mk_matrix_generate_stencil_scaled and the oracle's restatement of it give the same bits; 192 x 160 x 72 is large
+    enough for the selector to take the vsweep kernel by itself"""
+    dims = (192, 160, 72)
+    A = mk.Matrix.stencil(7, *dims, scale_seed=5)
+    rp, ci, v = oracle.stencil_csr(7, *dims, scale_seed=5)
+    grp, gci, gv = A.to_csr()
+    assert np.array_equal(grp, rp) and np.array_equal(gci, ci) and np.array_equal(gv.view(np.uint64), v.view(np.uint64))
+    assert A.info().kernel == mk.SPMV_VSWEEP
+    n = rp.size - 1
+    _vsweep_checks(A, rp, ci, v, n, np.random.default_rng(1), jacobi=False)
+    # rows [lo, hi) of the same operator generated as a block carry the same values (global row in the hash)
+    lo, hi = 1000, 50000
+    B = mk.Matrix.stencil(7, *dims, row_begin=lo, row_end=hi, scale_seed=5)
+    brp, bci, bv = B.to_csr()
+    assert np.array_equal(bci, ci[rp[lo]:rp[hi]]) and np.array_equal(bv.view(np.uint64), v[rp[lo]:rp[hi]].view(np.uint64))
+
+
+@pytest.mark.parametrize("n,hb", [(7, 3), (511, 2), (513, 3), (1025, 1), (100001, 3), (70000, 2)])
+def test_spmv_vsweep_ragged_banded(n, hb):
+    """banded matrices with random values (the contiguous sweep mode): odd row counts, fewer rows than a chunk, short rows
+    at both ends"""
+    rp, ci, v = oracle.banded_csr(n, hb)
+    rng = np.random.default_rng(n + hb)
+    rows = np.repeat(np.arange(n), np.diff(rp))
+    v = np.where(ci == rows, v + rng.uniform(0, 1, v.size), v * rng.uniform(0.2, 1.0, v.size))   # stays diagonally dominant
+    A = mk.Matrix.from_csr(n, n, rp, ci, v)
+    if A.info().value_patterns > 0 or A.info().index_patterns == 0:
+        assert n < 40          # a handful of rows: one (offsets, values) table entry per row, the pattern kernel serves it
+        return
+    _vsweep_checks(A, rp, ci, v, n, rng)
+
+
+@pytest.mark.parametrize("seed,P,K,nbase", [(1, 640, 9, 8), (2, 1024, 5, 7), (3, 96, 40, 6), (4, 2048, 12, 5), (5, 512, 21, 3)])
+def test_spmv_vsweep_random_patterns(seed, P, K, nbase):
+    """not a grid: a random base pattern with offsets a*P + b (unsymmetric, unsorted), every row a random sub-list of it,
+    every entry its own value; the kernel must reproduce the serial reference bit for bit"""
+    rng = np.random.default_rng(seed + 50)
+    n = P * K
+    bmax = min(P // 2 - 1, 300)
+    offs = []
+    while len(offs) < nbase:
+        o = int(rng.integers(-1, 2)) * P + int(rng.integers(-bmax, bmax + 1))
+        if o not in offs:
+            offs.append(o)
+    if 0 not in offs:
+        offs[int(rng.integers(0, nbase))] = 0
+    offs = np.array(offs)
+    masks = [np.ones(nbase, bool)] + [rng.random(nbase) < 0.7 for _ in range(19)]
+    for m in masks:
+        m[offs == 0] = True
+    which = rng.integers(0, len(masks), n)
+    which[rng.random(n) < 0.6] = 0
+    rows_c = []
+    for i in range(n):
+        keep = masks[which[i]] & (i + offs >= 0) & (i + offs < n)
+        rows_c.append(i + offs[keep])
+    lens = np.array([c.size for c in rows_c])
+    rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    ci = np.concatenate(rows_c).astype(np.int32)
+    v = rng.normal(size=ci.size)
+    rows = np.repeat(np.arange(n), lens)
+    v[ci == rows] = 4.0 + nbase + rng.uniform(0, 1, int((ci == rows).sum()))
+    A = mk.Matrix.from_csr(n, n, rp, ci, v)
+    _vsweep_checks(A, rp, ci, v, n, rng)
+
+
+def test_spmv_vsweep_eligibility():
+    rp, ci, v = oracle.stencil_csr(27, 12, 12, 12, scale_seed=2)      # 27 entries per row: the value stage does not fit
+    n = rp.size - 1
+    A = mk.Matrix.from_csr(n, n, rp, ci, v)
+    assert A.info().kernel == mk.SPMV_STREAM
+    with pytest.raises(mk.MkError, match="at most 8 entries"):
+        A.set_spmv_kernel(mk.SPMV_VSWEEP)
+    rp, ci, v = oracle.stencil_csr(7, 16, 16, 16)                      # constant coefficients: the table holds the values
+    B = mk.Matrix.from_csr(rp.size - 1, rp.size - 1, rp, ci, v)
+    with pytest.raises(mk.MkError):
+        B.set_spmv_kernel(mk.SPMV_VSWEEP)
+    rp, ci, v = oracle.stencil_csr(7, 16, 16, 16, scale_seed=1)
+    Cm = mk.Matrix.from_csr(rp.size - 1, rp.size - 1, rp, ci, v)
+    with pytest.raises(mk.MkError):
+        Cm.set_spmv_kernel(mk.SPMV_SWEEP)                              # no shared values: not the constant-coefficient sweep
+
+
 def test_spmv_sweep_kernel_eligibility():
     rp, ci, v = oracle.stencil_csr(7, 31, 29, 3)           # plane of 899 rows: odd stride, a lane's two rows would straddle planes
     n = rp.size - 1
