@@ -897,9 +897,9 @@ int mk_dist_pcg_solve(int R, mk_pcg **solvers, mk_dist_matrix **A, mk_vector **b
         MK_D(launch_sweep_cg_resid_x(&A[r]->diag, pv[r], W[r].r, x[r]->d, S0->precond == MK_PRECOND_JACOBI ? A[r]->diag.dinv : nullptr,
                                      W[r].buf, 1, 1, W[r].slab2, W[r].state, &nbk2));
       } else if (S0->precond == MK_PRECOND_JACOBI)
-        hipLaunchKernelGGL((pcg_update_xr_kernel<true>), dim3(vb[r]), dim3(kVecThreads), 0, c.stream, nl, pv[r], W[r].s, A[r]->diag.dinv, x[r]->d, W[r].r, W[r].buf, 1, 1, W[r].slab2, W[r].state, (int)nt_rows(nl));
+        hipLaunchKernelGGL((pcg_update_xr_kernel<true>), dim3(vb[r]), dim3(kVecThreads), 0, c.stream, nl, pv[r], W[r].s, A[r]->diag.dinv, x[r]->d, W[r].r, W[r].buf, 1, 1, W[r].slab2, W[r].state, vec_flags(nl));
       else
-        hipLaunchKernelGGL((pcg_update_xr_kernel<false>), dim3(vb[r]), dim3(kVecThreads), 0, c.stream, nl, pv[r], W[r].s, (const double *)nullptr, x[r]->d, W[r].r, W[r].buf, 1, 1, W[r].slab2, W[r].state, (int)nt_rows(nl));
+        hipLaunchKernelGGL((pcg_update_xr_kernel<false>), dim3(vb[r]), dim3(kVecThreads), 0, c.stream, nl, pv[r], W[r].s, (const double *)nullptr, x[r]->d, W[r].r, W[r].buf, 1, 1, W[r].slab2, W[r].state, vec_flags(nl));
       hipLaunchKernelGGL((finalize_slab_kernel<3>), dim3(1), dim3(kVecThreads), 0, c.stream, W[r].slab2, nbk2, buf3);
       bufs[r] = buf3;
     }
@@ -909,9 +909,9 @@ int mk_dist_pcg_solve(int R, mk_pcg **solvers, mk_dist_matrix **A, mk_vector **b
       bufs[r] = W[r].buf;
       if (pfuse[r]) continue;   // K3 rides in the next iteration's first sweep
       if (S0->precond == MK_PRECOND_JACOBI)
-        hipLaunchKernelGGL((pcg_update_p_kernel<true>), dim3(vb[r]), dim3(kVecThreads), 0, c.stream, nl, W[r].r, A[r]->diag.dinv, pv[r], W[r].buf + 4, 1, 1, two_norm, rel_change, W[r].state, W[r].norms, (int)nt_rows(nl));
+        hipLaunchKernelGGL((pcg_update_p_kernel<true>), dim3(vb[r]), dim3(kVecThreads), 0, c.stream, nl, W[r].r, A[r]->diag.dinv, pv[r], W[r].buf + 4, 1, 1, two_norm, rel_change, W[r].state, W[r].norms, vec_flags(nl));
       else
-        hipLaunchKernelGGL((pcg_update_p_kernel<false>), dim3(vb[r]), dim3(kVecThreads), 0, c.stream, nl, W[r].r, (const double *)nullptr, pv[r], W[r].buf + 4, 1, 1, two_norm, rel_change, W[r].state, W[r].norms, (int)nt_rows(nl));
+        hipLaunchKernelGGL((pcg_update_p_kernel<false>), dim3(vb[r]), dim3(kVecThreads), 0, c.stream, nl, W[r].r, (const double *)nullptr, pv[r], W[r].buf + 4, 1, 1, two_norm, rel_change, W[r].state, W[r].norms, vec_flags(nl));
       bufs[r] = W[r].buf;
     }
     if ((it + 1) % S0->check_every == 0) {

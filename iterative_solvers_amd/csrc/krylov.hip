@@ -170,21 +170,21 @@ int mk_pcg_solve(mk_pcg *S, const mk_matrix *A, const mk_vector *b, mk_vector *x
       if (!fuse_p) {
         stamp(it);
         if (dinv)
-          hipLaunchKernelGGL((pcg_update_p_kernel<true>), dim3(vb), dim3(kVecThreads), 0, c.stream, n, S->r, dinv, pcur, S->slab2, nb2, kSlabStride, S->two_norm, S->rel_change, S->state, S->norms, (int)nt_rows(n));
+          hipLaunchKernelGGL((pcg_update_p_kernel<true>), dim3(vb), dim3(kVecThreads), 0, c.stream, n, S->r, dinv, pcur, S->slab2, nb2, kSlabStride, S->two_norm, S->rel_change, S->state, S->norms, vec_flags(n));
         else
-          hipLaunchKernelGGL((pcg_update_p_kernel<false>), dim3(vb), dim3(kVecThreads), 0, c.stream, n, S->r, dinv, pcur, S->slab2, nb2, kSlabStride, S->two_norm, S->rel_change, S->state, S->norms, (int)nt_rows(n));
+          hipLaunchKernelGGL((pcg_update_p_kernel<false>), dim3(vb), dim3(kVecThreads), 0, c.stream, n, S->r, dinv, pcur, S->slab2, nb2, kSlabStride, S->two_norm, S->rel_change, S->state, S->norms, vec_flags(n));
       }
     } else {
     MK_TRY(launch_spmv_dot(A, S->p, S->s, S->slab1, &S->state->done, &nb1));
     stamp(it);
     if (dinv) {
-      hipLaunchKernelGGL((pcg_update_xr_kernel<true>), dim3(vb), dim3(kVecThreads), 0, c.stream, n, S->p, S->s, dinv, x->d, S->r, S->slab1, nb1, kSlabStride, S->slab2, S->state, (int)nt_rows(n));
+      hipLaunchKernelGGL((pcg_update_xr_kernel<true>), dim3(vb), dim3(kVecThreads), 0, c.stream, n, S->p, S->s, dinv, x->d, S->r, S->slab1, nb1, kSlabStride, S->slab2, S->state, vec_flags(n));
       stamp(it);
-      hipLaunchKernelGGL((pcg_update_p_kernel<true>), dim3(vb), dim3(kVecThreads), 0, c.stream, n, S->r, dinv, S->p, S->slab2, vb, kSlabStride, S->two_norm, S->rel_change, S->state, S->norms, (int)nt_rows(n));
+      hipLaunchKernelGGL((pcg_update_p_kernel<true>), dim3(vb), dim3(kVecThreads), 0, c.stream, n, S->r, dinv, S->p, S->slab2, vb, kSlabStride, S->two_norm, S->rel_change, S->state, S->norms, vec_flags(n));
     } else {
-      hipLaunchKernelGGL((pcg_update_xr_kernel<false>), dim3(vb), dim3(kVecThreads), 0, c.stream, n, S->p, S->s, dinv, x->d, S->r, S->slab1, nb1, kSlabStride, S->slab2, S->state, (int)nt_rows(n));
+      hipLaunchKernelGGL((pcg_update_xr_kernel<false>), dim3(vb), dim3(kVecThreads), 0, c.stream, n, S->p, S->s, dinv, x->d, S->r, S->slab1, nb1, kSlabStride, S->slab2, S->state, vec_flags(n));
       stamp(it);
-      hipLaunchKernelGGL((pcg_update_p_kernel<false>), dim3(vb), dim3(kVecThreads), 0, c.stream, n, S->r, dinv, S->p, S->slab2, vb, kSlabStride, S->two_norm, S->rel_change, S->state, S->norms, (int)nt_rows(n));
+      hipLaunchKernelGGL((pcg_update_p_kernel<false>), dim3(vb), dim3(kVecThreads), 0, c.stream, n, S->r, dinv, S->p, S->slab2, vb, kSlabStride, S->two_norm, S->rel_change, S->state, S->norms, vec_flags(n));
     }
     }
     if ((it + 1) % S->check_every == 0) {

@@ -69,6 +69,31 @@ __device__ __forceinline__ void vec_st(double2 *p, double2 v) {
   w.x = v.x; w.y = v.y;
   __builtin_nontemporal_store(w, reinterpret_cast<mk_d2v *>(p));
 }
+// which double2 a thread takes: layout 0 = grid-stride (consecutive blocks touch consecutive 4 KB pieces), layout 1 =
+// every block streams one contiguous range.  `nt` arguments of the kernels carry NT in bit 0 and the layout above it.
+template <typename F>
+__device__ __forceinline__ void vec_rows(int64_t n2, int layout, F f) {
+  if (layout == 0) {
+    for (int64_t i = (int64_t)blockIdx.x * kVecThreads + threadIdx.x; i < n2; i += (int64_t)gridDim.x * kVecThreads) f(i);
+  } else {
+    const int64_t per = ((n2 + gridDim.x - 1) / gridDim.x + kVecThreads - 1) / kVecThreads * kVecThreads;
+    const int64_t lo = (int64_t)blockIdx.x * per, hi = min(lo + per, n2);
+    if (layout == 1) {
+      for (int64_t i = lo + threadIdx.x; i < hi; i += kVecThreads) f(i);
+    } else {   // two pieces per trip: the loads of the second are issued before the stores of the first
+      int64_t i = lo + threadIdx.x;
+      for (; i + kVecThreads < hi; i += 2 * kVecThreads) { f(i); f(i + kVecThreads); }
+      if (i < hi) f(i);
+    }
+  }
+}
+// Measured, 512^3 (134 M rows): K2 1.32 ms grid-stride, 1.18 ms contiguous ranges, 1.17 ms with two pieces per trip
+// (4.9 -> 5.5 TB/s); K3 0.65 -> 0.60 ms.  At 256^3 (16.7 M rows) grid-stride is ahead by 3 %: the switch sits at 50 M rows.
+static inline int vec_flags(int64_t n) {
+  static const int env_layout = getenv("MK_VEC_LAYOUT") ? atoi(getenv("MK_VEC_LAYOUT")) : -1;
+  const int layout = env_layout >= 0 ? env_layout : (n > 50 * 1000 * 1000 ? 2 : 0);
+  return (int)nt_rows(n) | (layout << 1);
+}
 #define MK_VEC_LD(ptr) vec_ld<NT>(ptr)
 #define MK_VEC_ST(ptr, v) vec_st<NT>((ptr), (v))
 
@@ -104,7 +129,7 @@ __global__ __launch_bounds__(kVecThreads) void pcg_update_xr_kernel(int64_t n, c
   double2 *r2 = reinterpret_cast<double2 *>(r);
   auto rows = [&](auto tag) {
   constexpr bool NT = decltype(tag)::value;
-  for (int64_t i = (int64_t)blockIdx.x * kVecThreads + threadIdx.x; i < n2; i += (int64_t)gridDim.x * kVecThreads) {
+  vec_rows(n2, nt >> 1, [&](int64_t i) {
     const double2 pv = MK_VEC_LD(p2 + i), sv = MK_VEC_LD(s2 + i);
     double2 xv = MK_VEC_LD(x2 + i), rv = MK_VEC_LD(r2 + i);
     xv.x += alpha * pv.x; xv.y += alpha * pv.y;
@@ -116,9 +141,9 @@ __global__ __launch_bounds__(kVecThreads) void pcg_update_xr_kernel(int64_t n, c
     v[0] += rv.x * zx + rv.y * zy;
     v[1] += rv.x * rv.x + rv.y * rv.y;
     v[2] += xv.x * xv.x + xv.y * xv.y;
-  }
+  });
   };
-  if (nt) rows(std::true_type{}); else rows(std::false_type{});
+  if (nt & 1) rows(std::true_type{}); else rows(std::false_type{});
   if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
     const int64_t i = n - 1;
     const double xi = x[i] + alpha * p[i], ri = r[i] - alpha * s[i];
@@ -169,16 +194,16 @@ __global__ __launch_bounds__(kVecThreads) void pcg_update_p_kernel(int64_t n, co
   double2 *p2 = reinterpret_cast<double2 *>(p);
   auto rows = [&](auto tag) {
   constexpr bool NT = decltype(tag)::value;
-  for (int64_t i = (int64_t)blockIdx.x * kVecThreads + threadIdx.x; i < n2; i += (int64_t)gridDim.x * kVecThreads) {
+  vec_rows(n2, nt >> 1, [&](int64_t i) {
     double2 zv = MK_VEC_LD(r2 + i);
     if (PRECOND) { const double2 dv = MK_VEC_LD(d2 + i); zv.x *= dv.x; zv.y *= dv.y; }
     double2 pv = MK_VEC_LD(p2 + i);
     pv.x = beta * pv.x + zv.x;
     pv.y = beta * pv.y + zv.y;
     MK_VEC_ST(p2 + i, pv);
-  }
+  });
   };
-  if (nt) rows(std::true_type{}); else rows(std::false_type{});
+  if (nt & 1) rows(std::true_type{}); else rows(std::false_type{});
   if ((n & 1) && leader) {
     const int64_t i = n - 1;
     const double zi = PRECOND ? r[i] * dinv[i] : r[i];
@@ -206,6 +231,8 @@ static __global__ __launch_bounds__(kVecThreads) void finalize_slab_kernel(const
 namespace mk {
 
 static int vec_blocks(int64_t n) {
+  static const int env_blocks = getenv("MK_VEC_BLOCKS") ? atoi(getenv("MK_VEC_BLOCKS")) : 0;
+  if (env_blocks > 0) return std::min(env_blocks, kSlabStride);
   // Every block of the NEXT kernel re-reads all partials of this one (prologue reduce), so the
   // grid grows with the vector: at least 8 double2 per thread, one block per CU at the small end
   // (1M rows: 256 blocks; with 2048 blocks the prologues moved 4x the bytes of the update itself).
