@@ -151,7 +151,9 @@ def main():
     ap.add_argument("--cpu-iters", type=int, default=10)
     args = ap.parse_args()
 
-    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+    # MK_BENCH_FORCE_DIST=1 with --gpus 1 rehearses the whole self-launched multi-rank path (spawn, NCCL rendezvous,
+    # RCCL communicators of the library, row-block solve) on a one-GPU box
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or os.environ.get("MK_BENCH_FORCE_DIST")):
         raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
 
     rank = int(os.environ.get("RANK", "0"))

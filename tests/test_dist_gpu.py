@@ -173,6 +173,39 @@ def test_dist_27pt_rowblock_cg(world, precond, sweep):
     assert np.allclose(np.concatenate([x.get() for x in xs2]), o2["x"], rtol=1e-9, atol=1e-13)
 
 
+@pytest.mark.parametrize("world,precond", [(2, 0), (3, 1)])
+def test_dist_pcg_variable_coefficients_on_vsweep_diag_blocks(world, precond):
+    """variable-coefficient grid operator over z-slabs: the diag blocks run MK_SPMV_VSWEEP (values streamed through LDS),
+    the solver takes the unfused step (K1 + off-rank product, K2, K3)"""
+    dims = (32, 16, 24)
+    rp, ci, v = oracle.stencil_csr(7, *dims, scale_seed=4)
+    n = rp.size - 1
+    rng = np.random.default_rng(world)
+    rs = mkd.slab_row_start(*dims, world)
+    As = _blocks(rp, ci, v, n, rs, mkd.Comm.local_world(world))
+    for A in As:
+        A.set_spmv_kernel(mk.SPMV_VSWEEP)
+        assert A.diag_info().kernel == mk.SPMV_VSWEEP
+    xh = rng.normal(size=n)
+    xs = [A.vector(values=xh[rs[r]:rs[r + 1]]) for r, A in enumerate(As)]
+    ys = [A.vector(fill=-3.0) for A in As]
+    mkd.dist_spmv(As, xs, ys)
+    ref = oracle.csr_spmv(rp, ci, v, xh)
+    mag = oracle.csr_spmv(rp, ci, np.abs(v), np.abs(xh))
+    assert (np.abs(np.concatenate([y.get() for y in ys]) - ref) / mag).max() <= 1e-12
+    bh = rng.normal(size=n)
+    o = oracle.pcg(rp, ci, v, bh, tol=1e-9, precond=precond, maxit=2000, want_norms=True)
+    bs = [A.vector(values=bh[rs[k]:rs[k + 1]]) for k, A in enumerate(As)]
+    xs = [A.vector(fill=0.0) for A in As]
+    Ss = [mk.PCG(max_iter=2000, tol=1e-9, precond=precond, logging=1, check_every=7) for _ in As]
+    res = mkd.dist_pcg_solve(Ss, As, bs, xs)
+    assert res[0]["converged"] == 1 and abs(res[0]["iterations"] - o["iterations"]) <= 2
+    assert np.linalg.norm(np.concatenate([x.get() for x in xs]) - o["x"]) <= 1e-6 * np.linalg.norm(o["x"])
+    hist = Ss[0].residual_history(4000)
+    m = min(hist.size, o["rel_norms"].size, 30)
+    assert np.allclose(hist[:m], o["rel_norms"][:m], rtol=1e-8)
+
+
 def test_dist_pcg_rejects_nan_rhs():
     rp, ci, v = oracle.stencil_csr(5, 12, 12)
     n = rp.size - 1
