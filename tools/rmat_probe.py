@@ -33,3 +33,14 @@ for _ in range(reps):
 ms = mk.timer_stop() / reps
 sb = 12 * nnz + 20 * n + 4
 print(f"SpMV {ms*1e3:.0f} us = {sb/ms/1e6:.0f} GB/s effective ({sb/ms/1e6/8000:.3f} of 8 TB/s)")
+if os.environ.get("MK_PROBE_CHECK"):
+    import numpy as np
+    xh = np.random.default_rng(0).normal(size=n)
+    x.set(xh)
+    A.spmv(x, y)
+    got = y.get()
+    yx, xx = A.spmv_dot(x, y)
+    A.set_spmv_kernel(mk.SPMV_VECTOR)
+    A.spmv(x, y)
+    ref = y.get()
+    print("max |panel - vector| / max|ref| =", np.abs(got - ref).max() / np.abs(ref).max(), " dots rel err", abs(yx - ref @ xh) / np.abs(ref * xh).sum(), abs(xx - xh @ xh) / (xh @ xh))
