@@ -266,7 +266,8 @@ static int plan_sweep(mk_matrix *A, const std::vector<int> &tab, const std::vect
     auto fits = [&](int C) {
       const int sw = C + halo;
       const size_t lds = (size_t)kSweepNS * sw * 8 + ((size_t)len * C + 8) * 8 + (size_t)npat * 4;
-      return len <= 8 && lds <= 158 * 1024 && sw <= (C == 512 ? 1536 : 3072);
+      // (value positions are 32-bit: vb + 2 (tid + i T) must not wrap)
+      return len <= 8 && lds <= 158 * 1024 && sw <= (C == 512 ? 1536 : 3072) && A->nnz < ((int64_t)1 << 31) - 65536;
     };
     // measured (7-pt, product + dots): 512^3 C = 1024 1.955 ms / C = 512 2.05 ms; 256^3 (64 chunks of 1024 per plane)
     // 0.260 / 0.249 ms: the long chunk (window 2x instead of 3x the chunk) wins once a plane fills the chip with them

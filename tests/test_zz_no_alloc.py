@@ -30,6 +30,9 @@ def _matrix(case, size):
     elif case == "stream":
         A = mk.Matrix.stencil(7, *((48, 40, 36) if size else (14, 12, 10)), scale_seed=3)
         assert A.info().kernel == mk.SPMV_STREAM
+    elif case == "vsweep":
+        A = mk.Matrix.stencil(7, *((64, 48, 36) if size else (32, 16, 10)), scale_seed=7)
+        A.set_spmv_kernel(mk.SPMV_VSWEEP)
     elif case == "vector":
         A = mk.Matrix.stencil(5, *((300, 200) if size else (40, 30)), scale_seed=4)
         A.set_spmv_kernel(mk.SPMV_VECTOR, 8)
@@ -41,7 +44,7 @@ def _matrix(case, size):
     return A, rng.normal(size=A.nrows)
 
 
-@pytest.mark.parametrize("case", ["sweep", "pattern", "stream", "vector", "split"])
+@pytest.mark.parametrize("case", ["sweep", "pattern", "stream", "vsweep", "vector", "split"])
 def test_spmv_dot_static_matches_spmv_dot(case):
     for size in (1, 0, 1):                 # large, then smaller, then large again: stale scratch would show
         A, xh = _matrix(case, size)
