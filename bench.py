@@ -96,6 +96,129 @@ def cpu_baseline(kind, nx, ny, nz, precond, iters):
                       f"{os.environ.get('OMP_PROC_BIND', 'unset')}); matrix generation + warm-up {t1 - t0:.1f} s not counted"}
 
 
+def _median_time(fn, reps):
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        r = fn()
+        ts.append(time.perf_counter() - t0)
+    return float(np.median(ts)), r
+
+
+def cpu_configs(mk, which):
+    """`--cpu-configs c1,c2,c3`: SURVEY.md 8(d)'s per-config CPU baselines beside the GPU figure of the same config, one
+    JSON line per config (a separate mode: the default run prints its single line and times only the headline's baseline).
+    c1: full solve at tol 1e-6 and 1e-10; c2: SpMV + 50 iterations of Jacobi-PCG; c3: COO->CSR by the REFERENCE's own
+    convert_coo_to_csr (oracle/_ref, compiled from /root/reference/src/sparse_matrix.c) and by the oracle's restatement,
+    then SpMV.  CPU legs: the oracle's OpenMP kernels with the threads OpenMP finds; the conversion is serial like the
+    reference's.  Medians of 5 (GPU) / 3 (CPU), except the conversions, which run once."""
+    import oracle
+    model, phys = host_cpu()
+    threads = oracle.num_threads()
+    head = {"cpu_model": model, "physical_cores_of_the_machine": phys, "omp_threads": threads,
+            "OMP_NUM_THREADS": os.environ.get("OMP_NUM_THREADS", "unset"), "OMP_PROC_BIND": os.environ.get("OMP_PROC_BIND", "unset")}
+
+    def gpu_spmv_ms(A, reps=20):
+        x, y = mk.Vector(A.ncols, fill=1.0), mk.Vector(A.nrows)
+        for _ in range(3):
+            A.spmv(x, y)
+        ts = []
+        for _ in range(5):
+            mk.timer_start()
+            for _ in range(reps):
+                A.spmv(x, y)
+            ts.append(mk.timer_stop() / reps)
+        return float(np.median(ts))
+
+    def gpu_cg(A, precond, tol, maxit):
+        n = A.nrows
+        b, x = mk.Vector(n, fill=1.0), mk.Vector(n, fill=0.0)
+        ts, res = [], None
+        for _ in range(6):                                  # the first solve is the warm-up
+            S = mk.PCG(max_iter=maxit, tol=tol, precond=precond, logging=0, check_every=16 if tol > 0 else 50)
+            S.setup(A, b, x)
+            x.fill(0.0)                                     # x0 reset before every timed solve (8(d) timing rules)
+            mk.synchronize()
+            t0 = time.perf_counter()
+            res = S.solve(A, b, x)
+            mk.synchronize()
+            ts.append(time.perf_counter() - t0)
+        return float(np.median(ts[1:])), res
+
+    if "c1" in which:
+        rp, ci, v = oracle.stencil_csr(5, 1024, 1024, 1)
+        n = rp.size - 1
+        b = np.ones(n)
+        A = mk.Matrix.stencil(5, 1024, 1024, 1)
+        o = dict(head, config="c1: 2D 5-pt Poisson 1024^2, unpreconditioned CG (solver 50), b = 1, x0 = 0", rows=n, nnz=int(rp[-1]),
+                 cache_resident=True)
+        x = np.ones(n)
+        o["cpu_spmv_ms"] = round(_median_time(lambda: oracle.csr_spmv(rp, ci, v, x, omp=True), 5)[0] * 1e3, 3)
+        o["gpu_spmv_ms"] = round(gpu_spmv_ms(A, 100), 5)
+        for tol in (1e-6, 1e-10):
+            dt, r = _median_time(lambda: oracle.pcg(rp, ci, v, b, tol=tol, maxit=5000, omp=True), 3)
+            gdt, gr = gpu_cg(A, 0, tol, 5000)
+            o[f"tol{tol:g}"] = {"cpu_iterations": r["iterations"], "cpu_seconds": round(dt, 4), "cpu_it_per_s": round(r["iterations"] / dt, 1),
+                               "gpu_iterations": gr["iterations"], "gpu_seconds": round(gdt, 5), "gpu_it_per_s": round(gr["iterations"] / gdt, 1),
+                               "cpu_rel_res": r["rel_res_norm"], "gpu_rel_res": gr["rel_res_norm"]}
+        print(json.dumps(o), flush=True)
+        del A
+    if "c2" in which:
+        rp, ci, v = oracle.stencil_csr(7, 256, 256, 256)
+        n = rp.size - 1
+        b, x = np.ones(n), np.ones(n)
+        A = mk.Matrix.stencil(7, 256, 256, 256)
+        o = dict(head, config="c2: 3D 7-pt Laplacian 256^3, Jacobi-preconditioned CG (solver 51), 50 iterations", rows=n, nnz=int(rp[-1]))
+        o["cpu_spmv_ms"] = round(_median_time(lambda: oracle.csr_spmv(rp, ci, v, x, omp=True), 5)[0] * 1e3, 3)
+        o["gpu_spmv_ms"] = round(gpu_spmv_ms(A), 5)
+        dt, r = _median_time(lambda: oracle.pcg(rp, ci, v, b, precond=1, tol=0.0, maxit=50, omp=True), 3)
+        gdt, gr = gpu_cg(A, 1, 0.0, 50)
+        o.update(cpu_it_per_s=round(50 / dt, 2), gpu_it_per_s=round(50 / gdt, 1), cpu_rel_res=r["rel_res_norm"], gpu_rel_res=gr["rel_res_norm"])
+        print(json.dumps(o), flush=True)
+        del A
+    if "c3" in which:
+        scale, ne = 24, 1 << 28
+        t0 = time.perf_counter()
+        rows, cols, vals = oracle.rmat_coo(scale, ne, seed=42)
+        gen_s = time.perf_counter() - t0
+        nr = 1 << scale
+        o = dict(head, config="c3: R-MAT scale 24, 2^28 entries, seed 42 (unsorted COO, duplicates kept): COO->CSR + SpMV", rows=nr, nnz=ne,
+                 cpu_generate_s=round(gen_s, 1))
+        if oracle.have_ref():
+            t0 = time.perf_counter()
+            rrp, rci, rv = oracle.ref_coo_to_csr(nr, nr, rows, cols, vals)
+            o["cpu_reference_convert_ms"] = round((time.perf_counter() - t0) * 1e3, 1)
+            o["cpu_reference_convert_kind"] = "reference: convert_coo_to_csr of sparse_matrix.c, compiled into oracle/_ref, serial"
+        t0 = time.perf_counter()
+        rp, ci, v = oracle.coo_to_csr(nr, rows, cols, vals)
+        o["cpu_oracle_convert_ms"] = round((time.perf_counter() - t0) * 1e3, 1)
+        if oracle.have_ref():
+            o["reference_equals_oracle"] = bool(np.array_equal(rrp, rp) and np.array_equal(rci, ci) and np.array_equal(rv, v))
+            del rrp, rci, rv
+        del rows, cols, vals
+        x = np.ones(nr)
+        o["cpu_spmv_ms"] = round(_median_time(lambda: oracle.csr_spmv(rp, ci, v, x, omp=True), 5)[0] * 1e3, 2)
+        ts = []
+        for rep in range(4):
+            coo = mk.DeviceCOO.rmat(scale, ne, seed=42)
+            mk.synchronize()
+            mk.timer_start()
+            A = mk.Matrix.from_device_coo(coo)
+            ts.append(mk.timer_stop())
+            if rep < 3:
+                del A
+            del coo
+        o["gpu_convert_ms"] = round(float(np.median(ts[1:])), 3)
+        o["gpu_spmv_ms"] = round(gpu_spmv_ms(A, 10), 4)
+        o["gpu_spmv_kernel"] = KERNEL_NAMES.get(A.info().kernel)
+        y = mk.Vector(nr)
+        A.spmv(mk.Vector(nr, fill=1.0), y)
+        yc = oracle.csr_spmv(rp, ci, v, x, omp=True)
+        scale_y = oracle.csr_spmv(rp, ci, np.abs(v), x, omp=True)           # |A| |x|: the rounding scale of each row
+        o["gpu_vs_cpu_spmv_max_err_over_absA_absx"] = float(np.max(np.abs(y.get() - yc) / np.maximum(scale_y, 1e-300)))
+        print(json.dumps(o), flush=True)
+
+
 # ------------------------------------------------------------------------------ starting the ranks ourselves
 def _free_port():
     s = socket.socket()
@@ -149,6 +272,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=10)
+    ap.add_argument("--cpu-configs", default=None, help="comma list of c1,c2,c3: per-config CPU baselines beside the GPU (own mode)")
     args = ap.parse_args()
 
     # MK_BENCH_FORCE_DIST=1 with --gpus 1 rehearses the whole self-launched multi-rank path (spawn, NCCL rendezvous,
@@ -179,6 +303,9 @@ def main():
     if world > 1 or force_dist:
         from iterative_solvers_amd import distributed as mkd
         return mkd.bench_main(args, rank, local_rank, world, WORKLOADS, HBM_PEAK_GBS)
+
+    if args.cpu_configs:
+        return cpu_configs(mk, args.cpu_configs.split(","))
 
     traffic_db = {}
     tpath = os.path.join(ROOT, "profiles", "traffic.json")

@@ -13,6 +13,8 @@
 // Per pass: digit histogram per tile (reads 4 B/entry) -> exclusive scan of the
 // [digit][tile] table -> stable scatter (reads 16 B, writes 16 B per entry).
 // Inputs that are already row-sorted (the usual .mtx case) skip the sort entirely.
+#include <algorithm>
+#include <chrono>
 #include "mk_internal.h"
 
 namespace mk {
@@ -93,7 +95,18 @@ __global__ __launch_bounds__(kScanThreads) void scan_apply_kernel(const uint32_t
   }
 }
 
-int exclusive_scan_u32(const uint32_t *in, uint32_t *out, size_t n, uint32_t *total_out_dev) {
+// block sums of every level of the scan of n values
+static size_t scan_workspace_count(size_t n) {
+  size_t total = 0;
+  while (n > (size_t)kScanChunk) {
+    n = (n + kScanChunk - 1) / kScanChunk;
+    total += n;
+  }
+  return total;
+}
+
+// scan with the caller's workspace (scan_workspace_count(n) words): no allocation, nothing waits for the stream
+static int exclusive_scan_u32_ws(const uint32_t *in, uint32_t *out, size_t n, uint32_t *total_out_dev, uint32_t *ws) {
   Context &c = ctx();
   if (n == 0) {
     if (total_out_dev) MK_HIP(hipMemsetAsync(total_out_dev, 0, sizeof(uint32_t), c.stream));
@@ -105,18 +118,23 @@ int exclusive_scan_u32(const uint32_t *in, uint32_t *out, size_t n, uint32_t *to
     return MK_OK;
   }
   const size_t nchunks = (n + kScanChunk - 1) / kScanChunk;
-  uint32_t *sums = nullptr;
-  MK_TRY(dev_alloc(&sums, nchunks));
+  uint32_t *sums = ws;
   hipLaunchKernelGGL(scan_reduce_kernel, dim3((unsigned)nchunks), dim3(kScanThreads), 0, c.stream, in, n, sums);
-  int rc = exclusive_scan_u32(sums, sums, nchunks, total_out_dev);  // in place is fine for both scan forms
-  if (rc == MK_OK) {
-    hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)nchunks), dim3(kScanThreads), 0, c.stream, in, out, n, sums);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) rc = fail(MK_ERR_HIP, "scan_apply: %s", hipGetErrorString(e));
+  MK_TRY(exclusive_scan_u32_ws(sums, sums, nchunks, total_out_dev, ws + nchunks));  // in place is fine for both scan forms
+  hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)nchunks), dim3(kScanThreads), 0, c.stream, in, out, n, sums);
+  MK_HIP(hipGetLastError());
+  return MK_OK;
+}
+
+int exclusive_scan_u32(const uint32_t *in, uint32_t *out, size_t n, uint32_t *total_out_dev) {
+  uint32_t *ws = nullptr;
+  const size_t nws = scan_workspace_count(n);
+  if (nws) MK_TRY(dev_alloc(&ws, nws));
+  const int rc = exclusive_scan_u32_ws(in, out, n, total_out_dev, ws);
+  if (ws) {   // still in use by queued kernels: free after they drain
+    (void)hipStreamSynchronize(ctx().stream);
+    dev_free(ws);
   }
-  // sums is still in use by queued kernels: free after they drain
-  (void)hipStreamSynchronize(c.stream);
-  dev_free(sums);
   return rc;
 }
 
@@ -130,12 +148,23 @@ struct CooCheck {
 __global__ void coo_check_kernel(int64_t nnz, int64_t nrows, int64_t ncols, const int *__restrict__ rows,
                                  const int *__restrict__ cols, CooCheck *out) {
   int unsorted = 0, bad_row = 0, bad_col = 0;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += (int64_t)gridDim.x * blockDim.x) {
-    const int r = rows[i], cc = cols[i];
-    if (r < 0 || r >= nrows) bad_row = 1;
-    if (cc < 0 || cc >= ncols) bad_col = 1;
-    if (i > 0 && rows[i - 1] > r) unsorted = 1;
+  // four consecutive entries per thread (16-byte loads) plus the row in front of them
+  const int64_t nq = nnz / 4;
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (int64_t)gridDim.x * blockDim.x) {
+    const int4 r = *reinterpret_cast<const int4 *>(rows + 4 * q);
+    const int4 cc = *reinterpret_cast<const int4 *>(cols + 4 * q);
+    const int prev = q ? rows[4 * q - 1] : r.x;
+    if ((r.x | r.y | r.z | r.w) < 0 || r.x >= nrows || r.y >= nrows || r.z >= nrows || r.w >= nrows) bad_row = 1;
+    if ((cc.x | cc.y | cc.z | cc.w) < 0 || cc.x >= ncols || cc.y >= ncols || cc.z >= ncols || cc.w >= ncols) bad_col = 1;
+    if (prev > r.x || r.x > r.y || r.y > r.z || r.z > r.w) unsorted = 1;
   }
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    for (int64_t i = 4 * nq; i < nnz; i++) {
+      const int r = rows[i], cc = cols[i];
+      if (r < 0 || r >= nrows) bad_row = 1;
+      if (cc < 0 || cc >= ncols) bad_col = 1;
+      if (i > 0 && rows[i - 1] > r) unsorted = 1;
+    }
   if (__any(unsorted) && (threadIdx.x & 63) == 0) out->unsorted = 1;
   if (__any(bad_row) && (threadIdx.x & 63) == 0) out->bad_row = 1;
   if (__any(bad_col) && (threadIdx.x & 63) == 0) out->bad_col = 1;
@@ -146,24 +175,49 @@ constexpr int kRadixBits = 8;
 constexpr int kRadix = 1 << kRadixBits;
 constexpr int kSortThreads = 512;
 constexpr int kSortWaves = kSortThreads / 64;
-constexpr int kSortItems = 16;
+constexpr int kSortItems = 8;
 constexpr int kSortTile = kSortThreads * kSortItems;  // 8192 entries per block
 constexpr int kWaveSpan = 64 * kSortItems;            // consecutive entries owned by one wave
 
-// table[digit * ntiles + tile] = number of keys of that digit in the tile
+// table[digit * ntiles + tile] = number of keys of that digit in the tile.  One block counts kHistTiles consecutive tiles,
+// one after the other, and then writes kHistTiles neighbouring table entries per digit (the table is digit-major for the
+// scan: a block per tile wrote 256 isolated 4-byte words).
+constexpr int kHistTiles = 8;
 __global__ __launch_bounds__(kSortThreads) void radix_hist_kernel(const int *__restrict__ keys, int64_t n, int shift,
                                                                   unsigned mask, uint32_t *__restrict__ table, int ntiles) {
-  __shared__ unsigned int h[kRadix];
-  for (int i = threadIdx.x; i < kRadix; i += kSortThreads) h[i] = 0;
+  __shared__ unsigned int h[kHistTiles][kRadix];
+  for (int i = threadIdx.x; i < kHistTiles * kRadix; i += kSortThreads) (&h[0][0])[i] = 0;
   __syncthreads();
-  const int64_t base = (int64_t)blockIdx.x * kSortTile;
+  const int tile0 = blockIdx.x * kHistTiles;
+  for (int t = 0; t < kHistTiles && tile0 + t < ntiles; t++) {
+    const int64_t base = (int64_t)(tile0 + t) * kSortTile;
+    if (base + kSortTile <= n) {   // whole tile: 16-byte loads (the count does not depend on the order inside the tile)
+      typedef int i4v_t __attribute__((ext_vector_type(4)));
+      const i4v_t *k4 = reinterpret_cast<const i4v_t *>(keys + base);
+      constexpr int NV = kSortItems / 4;
+      i4v_t v[NV];
+#pragma unroll
+      for (int k = 0; k < NV; k++) v[k] = __builtin_nontemporal_load(k4 + k * kSortThreads + threadIdx.x);
+#pragma unroll
+      for (int k = 0; k < NV; k++) {
+        atomicAdd(&h[t][((unsigned)v[k].x >> shift) & mask], 1u);
+        atomicAdd(&h[t][((unsigned)v[k].y >> shift) & mask], 1u);
+        atomicAdd(&h[t][((unsigned)v[k].z >> shift) & mask], 1u);
+        atomicAdd(&h[t][((unsigned)v[k].w >> shift) & mask], 1u);
+      }
+    } else {
 #pragma unroll 4
-  for (int k = 0; k < kSortItems; k++) {
-    const int64_t i = base + (int64_t)k * kSortThreads + threadIdx.x;
-    if (i < n) atomicAdd(&h[((unsigned)keys[i] >> shift) & mask], 1u);
+      for (int k = 0; k < kSortItems; k++) {
+        const int64_t i = base + (int64_t)k * kSortThreads + threadIdx.x;
+        if (i < n) atomicAdd(&h[t][((unsigned)keys[i] >> shift) & mask], 1u);
+      }
+    }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < kRadix; i += kSortThreads) table[(size_t)i * ntiles + blockIdx.x] = h[i];
+  for (int i = threadIdx.x; i < kHistTiles * kRadix; i += kSortThreads) {
+    const int d = i / kHistTiles, t = i % kHistTiles;
+    if (tile0 + t < ntiles) table[(size_t)d * ntiles + tile0 + t] = h[t][d];
+  }
 }
 
 // Stable scatter.  Order inside a tile is (wave, item, lane): wave w owns entries
@@ -181,24 +235,49 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
   __shared__ unsigned int gbase[kRadix];             // global offset of (digit, this tile)
   __shared__ unsigned int lstart[kRadix];            // first tile-local sorted slot of the digit
   __shared__ __attribute__((aligned(16))) unsigned long long stage[kSortTile];   // 64 KB
+  // Blocks are dealt round-robin over the 8 XCDs: block b takes tile (b % 8) * ceil(ntiles / 8) + b / 8, so that one XCD
+  // works through a contiguous range of tiles in order.  The pieces that consecutive tiles write into one digit's output
+  // range are adjacent: written through the same L2 they merge into whole lines before they leave it.
+  const int per_xcd = (ntiles + 7) / 8;
+  const int tile = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+  if (tile >= ntiles) return;
   for (int i = threadIdx.x; i < kSortWaves * kRadix; i += kSortThreads) (&cnt[0][0])[i] = 0;
-  for (int i = threadIdx.x; i < kRadix; i += kSortThreads) gbase[i] = table_scanned[(size_t)i * ntiles + blockIdx.x];
+  for (int i = threadIdx.x; i < kRadix; i += kSortThreads) gbase[i] = table_scanned[(size_t)i * ntiles + tile];
   __syncthreads();
 
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int64_t tbase = (int64_t)blockIdx.x * kSortTile;
+  const int64_t tbase = (int64_t)tile * kSortTile;
   const int64_t wbase = tbase + (int64_t)w * kWaveSpan;
   const int tile_n = (int)min((int64_t)kSortTile, n - tbase);
   const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   unsigned int slot[kSortItems];    // rank among equal digits, later the tile-local sorted slot
-  int key[kSortItems];
+  unsigned long long kcv[kSortItems];   // col << 32 | key
+  double valv[kSortItems];
+  // everything the tile needs is requested up front: the column and value loads fly while the keys are ranked
+  {
+    int key[kSortItems];
+#pragma unroll
+    for (int k = 0; k < kSortItems; k++) {
+      const int64_t i = min(wbase + (int64_t)k * 64 + lane, n - 1);
+      key[k] = __builtin_nontemporal_load(keys_in + i);
+    }
+#pragma unroll
+    for (int k = 0; k < kSortItems; k++) {
+      const int64_t i = min(wbase + (int64_t)k * 64 + lane, n - 1);
+      kcv[k] = ((unsigned long long)(unsigned)__builtin_nontemporal_load(cols_in + i) << 32) | (unsigned)key[k];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < kSortItems; k++) {
+    const int64_t i = min(wbase + (int64_t)k * 64 + lane, n - 1);
+    valv[k] = __builtin_nontemporal_load(vals_in + i);
+  }
   volatile unsigned int *mycnt = cnt[w];
 #pragma unroll
   for (int k = 0; k < kSortItems; k++) {
     const int64_t i = wbase + (int64_t)k * 64 + lane;
     const bool valid = i < n;
-    key[k] = valid ? keys_in[i] : 0;
-    const unsigned d = ((unsigned)key[k] >> shift) & mask;
+    const unsigned d = ((unsigned)kcv[k] >> shift) & mask;
     unsigned long long peers = __ballot(valid);
 #pragma unroll
     for (int b = 0; b < kRadixBits; b++) {
@@ -213,8 +292,10 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
     __builtin_amdgcn_wave_barrier();
   }
   __syncthreads();
-  // per digit: exclusive offsets over waves, and the digit's total -> exclusive scan over digits
-  unsigned total = 0;
+  // per digit: exclusive offsets over waves, and the digit's total -> exclusive scan over the 256 digits (threads 0..255 =
+  // waves 0..3: shuffle scan inside each wave, the three wave totals through LDS)
+  __shared__ unsigned int wtot[4];
+  unsigned total = 0, incl = 0;
   if (threadIdx.x < kRadix) {
 #pragma unroll
     for (int ww = 0; ww < kSortWaves; ww++) {
@@ -222,26 +303,30 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
       cnt[ww][threadIdx.x] = total;
       total += t;
     }
-    lstart[threadIdx.x] = total;
+    incl = total;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const unsigned t = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += t;
+    }
+    if (lane == 63) wtot[w] = incl;
   }
   __syncthreads();
-  for (int off = 1; off < kRadix; off <<= 1) {
-    unsigned t = 0;
-    if (threadIdx.x < kRadix && threadIdx.x >= (unsigned)off) t = lstart[threadIdx.x - off];
-    __syncthreads();
-    if (threadIdx.x < kRadix) lstart[threadIdx.x] += t;
-    __syncthreads();
+  if (threadIdx.x < kRadix) {
+    unsigned add = 0;
+#pragma unroll
+    for (int ww = 0; ww < 3; ww++) add += (ww < w) ? wtot[ww] : 0u;
+    lstart[threadIdx.x] = add + incl - total;   // exclusive
   }
-  if (threadIdx.x < kRadix) lstart[threadIdx.x] -= total;   // inclusive -> exclusive
   __syncthreads();
   // round A: (key, col) pairs through LDS
 #pragma unroll
   for (int k = 0; k < kSortItems; k++) {
     const int64_t i = wbase + (int64_t)k * 64 + lane;
     if (i < n) {
-      const unsigned d = ((unsigned)key[k] >> shift) & mask;
+      const unsigned d = ((unsigned)kcv[k] >> shift) & mask;
       slot[k] = lstart[d] + cnt[w][d] + slot[k];
-      stage[slot[k]] = ((unsigned long long)(unsigned)cols_in[i] << 32) | (unsigned)key[k];
+      stage[slot[k]] = kcv[k];
     }
   }
   __syncthreads();
@@ -254,6 +339,9 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
       const unsigned long long kc = stage[j];
       const unsigned d = ((unsigned)kc >> shift) & mask;
       gpos[k] = gbase[d] + ((unsigned)j - lstart[d]);
+      // plain stores: the pieces merge in L2 (nontemporal stores: 11.4 -> 14.1 ms for 2^28 entries).  Carrying the
+      // (key, col) pair as one 8-byte word between the passes measured slower as well (scatter 2.46 -> 2.62 ms per pass,
+      // and the histogram of the next pass reads twice the bytes)
       keys_out[gpos[k]] = (int)(unsigned)kc;
       cols_out[gpos[k]] = (int)(unsigned)(kc >> 32);
     }
@@ -264,7 +352,7 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
 #pragma unroll
   for (int k = 0; k < kSortItems; k++) {
     const int64_t i = wbase + (int64_t)k * 64 + lane;
-    if (i < n) vstage[slot[k]] = vals_in[i];
+    if (i < n) vstage[slot[k]] = valv[k];
   }
   __syncthreads();
 #pragma unroll
@@ -279,12 +367,25 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(
 
 // row_pointers from the sorted keys: entry i opens every row in (rows[i-1], rows[i]]
 __global__ void rowptr_from_sorted_kernel(int64_t nnz, int64_t nrows, const int *__restrict__ rows, int *__restrict__ rowptr) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += (int64_t)gridDim.x * blockDim.x) {
-    const int r = rows[i];
-    const int prev = (i == 0) ? -1 : rows[i - 1];
-    for (int q = prev + 1; q <= r; q++) rowptr[q] = (int)i;
-    if (i == nnz - 1)
-      for (int64_t q = (int64_t)r + 1; q <= nrows; q++) rowptr[q] = (int)nnz;
+  // four consecutive entries per thread (one 16-byte load) plus the entry in front of them
+  const int64_t nq = (nnz + 3) / 4;
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i0 = q * 4;
+    int r[4];
+    if (i0 + 4 <= nnz) {
+      const int4 v = *reinterpret_cast<const int4 *>(rows + i0);
+      r[0] = v.x; r[1] = v.y; r[2] = v.z; r[3] = v.w;
+    } else {
+      for (int j = 0; j < 4; j++) r[j] = (i0 + j < nnz) ? rows[i0 + j] : 0;
+    }
+    int prev = (i0 == 0) ? -1 : rows[i0 - 1];
+    for (int j = 0; j < 4 && i0 + j < nnz; j++) {
+      const int64_t i = i0 + j;
+      for (int t = prev + 1; t <= r[j]; t++) rowptr[t] = (int)i;
+      if (i == nnz - 1)
+        for (int64_t t = (int64_t)r[j] + 1; t <= nrows; t++) rowptr[t] = (int)nnz;
+      prev = r[j];
+    }
   }
 }
 
@@ -298,16 +399,23 @@ static int key_bits(int64_t nrows) {
   return bits;
 }
 
+static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+#define MK_TR(label) do { if (trace) { (void)hipStreamSynchronize(c.stream); double t_ = now_ms(); fprintf(stderr, "  [convert] %-28s %8.3f ms\n", label, t_ - t_prev); t_prev = t_; } } while (0)
 int device_coo_to_csr(mk_coo *coo, mk_matrix *A, int **sorted_rows_out) {
   Context &c = ctx();
+  static const int trace = getenv("MK_CONVERT_TRACE") ? atoi(getenv("MK_CONVERT_TRACE")) : 0;
+  double t_prev = now_ms();
   const int64_t nnz = coo->nnz, nrows = coo->nrows;
   if (nnz > (int64_t)0x7fffffff) return fail(MK_ERR_UNSUPPORTED, "local nnz %lld exceeds int32 row pointers", (long long)nnz);
   A->nrows = nrows; A->ncols = coo->ncols; A->nnz = nnz;
   MK_TRY(dev_alloc(&A->rowptr, (size_t)nrows + 1));
+  MK_TR("alloc rowptr");
 
   // 1. validate + detect the already-sorted case
-  CooCheck h{0, 0, 0}, *d_chk = nullptr;
-  MK_TRY(dev_alloc(&d_chk, 1));
+  // flags in the context's reduction scratch (nothing else runs on the stream during a conversion), read back through
+  // the pinned staging buffer: no allocation, no pageable copy
+  CooCheck *d_chk = reinterpret_cast<CooCheck *>(c.slab);
+  CooCheck &h = *static_cast<CooCheck *>(c.pinned);
   MK_HIP(hipMemsetAsync(d_chk, 0, sizeof(CooCheck), c.stream));
   if (nnz > 0) {
     int blocks = (int)std::min<int64_t>((nnz + 255) / 256, 4096);
@@ -315,62 +423,98 @@ int device_coo_to_csr(mk_coo *coo, mk_matrix *A, int **sorted_rows_out) {
   }
   MK_HIP(hipMemcpyAsync(&h, d_chk, sizeof(h), hipMemcpyDeviceToHost, c.stream));
   MK_HIP(hipStreamSynchronize(c.stream));
-  dev_free(d_chk);
+  MK_TR("check");
   if (h.bad_row) return fail(MK_ERR_INVALID, "COO row index outside [0,%lld)", (long long)nrows);
   if (h.bad_col) return fail(MK_ERR_INVALID, "COO column index outside [0,%lld)", (long long)coo->ncols);
 
   int *keys = coo->rows, *cols = coo->cols;
   double *vals = coo->vals;
+  char *scratch = nullptr;   // one allocation for everything that does not outlive the call (hipFree costs 0.2 ms a call)
+  std::vector<void *> spent;   // the caller's arrays once the sorted entries live elsewhere
   if (h.unsorted) {
-    // 2. stable LSD radix sort on the row key
-    int *keys2 = nullptr, *cols2 = nullptr;
-    double *vals2 = nullptr;
-    uint32_t *table = nullptr;
-    const int ntiles = (int)((nnz + kSortTile - 1) / kSortTile);
-    MK_TRY(dev_alloc(&keys2, (size_t)nnz));
-    MK_TRY(dev_alloc(&cols2, (size_t)nnz));
-    MK_TRY(dev_alloc(&vals2, (size_t)nnz));
-    MK_TRY(dev_alloc(&table, (size_t)kRadix * ntiles));
+    // 2. stable LSD radix sort on the row key.  Passes alternate between a scratch set S and the final set F, arranged so
+    // that the LAST pass writes F: the column and value arrays of F are allocated on their own (they become the matrix),
+    // the keys of F, all of S, the digit table and the scan workspace share the scratch block.
     const int bits = key_bits(nrows);
     const int passes = (bits + kRadixBits - 1) / kRadixBits;
+    const int ntiles = (int)((nnz + kSortTile - 1) / kSortTile);
+    const size_t ntab = (size_t)kRadix * ntiles;
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { const size_t o = off; off += (bytes + 511) & ~(size_t)255; return o; };   // >= 256 B slack each
+    const size_t o_keys_f = carve((size_t)nnz * 4);
+    const size_t o_keys_s = passes > 1 ? carve((size_t)nnz * 4) : 0, o_cols_s = passes > 1 ? carve((size_t)nnz * 4) : 0;
+    const size_t o_vals_s = passes > 1 ? carve((size_t)nnz * 8) : 0;
+    const size_t o_table = carve(ntab * 4), o_ws = carve(scan_workspace_count(ntab) * 4);
+    MK_TRY(dev_alloc(&scratch, off));
+    int *cols_f = nullptr;
+    double *vals_f = nullptr;
+    int rc = dev_alloc(&cols_f, (size_t)nnz);
+    if (rc == MK_OK) rc = dev_alloc(&vals_f, (size_t)nnz);
+    if (rc != MK_OK) { dev_free(scratch); dev_free(cols_f); return rc; }
+    int *keys_f = reinterpret_cast<int *>(scratch + o_keys_f);
+    int *keys_s = reinterpret_cast<int *>(scratch + o_keys_s), *cols_s = reinterpret_cast<int *>(scratch + o_cols_s);
+    double *vals_s = reinterpret_cast<double *>(scratch + o_vals_s);
+    uint32_t *table = reinterpret_cast<uint32_t *>(scratch + o_table), *ws = reinterpret_cast<uint32_t *>(scratch + o_ws);
+    MK_TR("alloc sort buffers");
+    spent.push_back(keys);
+    spent.push_back(cols);
+    spent.push_back(vals);
     int shift = 0;
     for (int p = 0; p < passes; p++) {
       // spread the key bits evenly over the passes
       const int pb = (bits - shift + (passes - p) - 1) / (passes - p);
       const unsigned mask = (1u << pb) - 1u;
-      hipLaunchKernelGGL(radix_hist_kernel, dim3(ntiles), dim3(kSortThreads), 0, c.stream, keys, nnz, shift, mask, table, ntiles);
-      MK_HIP(hipGetLastError());
-      MK_TRY(exclusive_scan_u32(table, table, (size_t)kRadix * ntiles, nullptr));
-      hipLaunchKernelGGL(radix_scatter_kernel, dim3(ntiles), dim3(kSortThreads), 0, c.stream, keys, cols, vals, keys2, cols2,
-                         vals2, nnz, shift, mask, table, ntiles);
-      MK_HIP(hipGetLastError());
-      std::swap(keys, keys2);
-      std::swap(cols, cols2);
-      std::swap(vals, vals2);
+      const bool to_f = ((passes - 1 - p) % 2) == 0;
+      int *keys_o = to_f ? keys_f : keys_s, *cols_o = to_f ? cols_f : cols_s;
+      double *vals_o = to_f ? vals_f : vals_s;
+      hipLaunchKernelGGL(radix_hist_kernel, dim3((ntiles + kHistTiles - 1) / kHistTiles), dim3(kSortThreads), 0, c.stream, keys, nnz, shift, mask, table, ntiles);
+      MK_TR("hist");
+      rc = exclusive_scan_u32_ws(table, table, ntab, nullptr, ws);
+      if (rc != MK_OK) break;
+      MK_TR("scan");
+      hipLaunchKernelGGL(radix_scatter_kernel, dim3((ntiles + 7) / 8 * 8), dim3(kSortThreads), 0, c.stream, keys, cols, vals, keys_o, cols_o,
+                         vals_o, nnz, shift, mask, table, ntiles);
+      keys = keys_o;
+      cols = cols_o;
+      vals = vals_o;
       shift += pb;
+      MK_TR("scatter");
     }
-    MK_HIP(hipStreamSynchronize(c.stream));
-    dev_free(keys2);
-    dev_free(cols2);
-    dev_free(vals2);
-    dev_free(table);
+    if (rc == MK_OK && hipGetLastError() != hipSuccess) rc = fail(MK_ERR_HIP, "COO -> CSR: a sort kernel failed to launch");
+    if (rc != MK_OK) {
+      (void)hipStreamSynchronize(c.stream);
+      dev_free(scratch); dev_free(cols_f); dev_free(vals_f);
+      return rc;
+    }
   }
   // 3. row pointers from the sorted keys
   if (nnz == 0) {
     int blocks = (int)std::min<int64_t>((nrows + 1 + 255) / 256, 4096);
     hipLaunchKernelGGL(fill_int_kernel, dim3(blocks), dim3(256), 0, c.stream, A->rowptr, nrows + 1, 0);
   } else {
-    int blocks = (int)std::min<int64_t>((nnz + 255) / 256, 8192);
+    int blocks = (int)std::min<int64_t>(((nnz + 3) / 4 + 255) / 256, 8192);
     hipLaunchKernelGGL(rowptr_from_sorted_kernel, dim3(blocks), dim3(256), 0, c.stream, nnz, nrows, keys, A->rowptr);
   }
   MK_HIP(hipGetLastError());
   A->col = cols;
   A->val = vals;
-  if (sorted_rows_out) {
+  if (scratch) {   // sorted: keys live in the scratch block
+    if (sorted_rows_out) {
+      int *copy = nullptr;
+      MK_TRY(dev_alloc(&copy, (size_t)nnz));
+      MK_HIP(hipMemcpyAsync(copy, keys, sizeof(int) * (size_t)nnz, hipMemcpyDeviceToDevice, c.stream));
+      *sorted_rows_out = copy;
+    }
+    MK_HIP(hipStreamSynchronize(c.stream));
+    dev_free(scratch);
+    for (void *q : spent) dev_free(q);
+    MK_TR("rowptr + free");
+  } else if (sorted_rows_out) {
     *sorted_rows_out = keys;
   } else {
     MK_HIP(hipStreamSynchronize(c.stream));
     dev_free(keys);
+    MK_TR("free keys");
   }
   coo->rows = nullptr; coo->cols = nullptr; coo->vals = nullptr; coo->nnz = 0;
   return MK_OK;
@@ -618,9 +762,35 @@ int build_transpose(const mk_matrix *A, mk_matrix **out) {
 // densely used lines (R-MAT scale 24: the 2^18 hottest columns carry 69 % of the entries).  The product reads
 // xg[j] = x[order[j]] (one gather pass per product) through col2 = perm[col]: the same values multiplied and added
 // in the same order -> bit-identical to the product on the original numbering; col[] stays for mk_matrix_get_csr.
-static __global__ void col_degree_kernel(int64_t nnz, const int *__restrict__ col, unsigned *__restrict__ deg) {
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nnz; e += (int64_t)gridDim.x * blockDim.x)
-    atomicAdd(&deg[col[e]], 1u);
+// Column degrees.  On a power-law matrix a handful of columns take a large share of the entries, and global atomics on one
+// address serialise (31 ms for R-MAT scale 24 with one atomic per entry).  Each block therefore counts in an LDS table first:
+// a column claims the slot it hashes to, later entries of the same column count there, a column that finds its slot taken
+// goes to global memory directly.  The table is flushed once per block.
+constexpr int kDegSlots = 8192;
+static __global__ __launch_bounds__(256) void col_degree_kernel(int64_t nnz, const int *__restrict__ col, unsigned *__restrict__ deg) {
+  __shared__ int skey[kDegSlots];
+  __shared__ unsigned scnt[kDegSlots];
+  for (int i = threadIdx.x; i < kDegSlots; i += blockDim.x) {
+    skey[i] = -1;
+    scnt[i] = 0;
+  }
+  __syncthreads();
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nnz; e += (int64_t)gridDim.x * blockDim.x) {
+    const int c = col[e];
+    const int slot = (int)(((unsigned)c * 2654435761u) >> 19);   // top 13 bits
+    int owner = skey[slot];
+    if (owner == -1) {
+      owner = atomicCAS(&skey[slot], -1, c);
+      if (owner == -1) owner = c;
+    }
+    if (owner == c)
+      atomicAdd(&scnt[slot], 1u);
+    else
+      atomicAdd(&deg[c], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < kDegSlots; i += blockDim.x)
+    if (scnt[i]) atomicAdd(&deg[skey[i]], scnt[i]);
 }
 
 // key 0 = hottest: 4 classes per power of two of the degree (two mantissa bits), columns nobody refers to last
@@ -665,7 +835,7 @@ int build_column_relabel(mk_matrix *A) {
     (void)hipMemsetAsync(deg, 0, sizeof(unsigned) * (size_t)nc, c.stream);
     const int be = (int)std::max<int64_t>(1, std::min<int64_t>((nnz + 255) / 256, 8192));
     const int bc = (int)std::max<int64_t>(1, std::min<int64_t>((nc + 255) / 256, 4096));
-    hipLaunchKernelGGL(col_degree_kernel, dim3(be), dim3(256), 0, c.stream, nnz, A->col, deg);
+    hipLaunchKernelGGL(col_degree_kernel, dim3(std::min(be, 2048)), dim3(256), 0, c.stream, nnz, A->col, deg);
     hipLaunchKernelGGL(col_class_kernel, dim3(bc), dim3(256), 0, c.stream, nc, deg, d.rows, d.cols, d.vals);
     rc = device_coo_to_csr(&d, &M, nullptr);   // stable: columns of one class keep their order
     if (rc == MK_OK) rc = dev_alloc(&A->col2, (size_t)nnz);
