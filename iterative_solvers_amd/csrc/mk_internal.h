@@ -79,7 +79,8 @@ struct SweepArgs {
 };
 struct SweepEntry {   // one entry of the base pattern.  Device table: 4 copies x 32 entries (padded with zeros);
   int off;            // copy c serves the steps whose plane sits in ring slot c: off = byte offset in the LDS ring
-  int pad;            // of the x entry this matrix entry multiplies, for the lane that owns row r0 of the chunk
+  int off1;           // of the x entry this matrix entry multiplies, for the lane that owns row r0 of the chunk (off1: the
+                      // operand of the lane's second row, spmv_sweep_kernel's de-interleaved slabs only)
   double v;
 };
 

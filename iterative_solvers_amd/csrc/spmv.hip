@@ -297,7 +297,16 @@ static int plan_sweep(mk_matrix *A, const std::vector<int> &tab, const std::vect
   memset(E, 0, sizeof(E));
   for (int c4 = 0; c4 < 4; c4++)
     for (int u = 0; u < len; u++) {
-      E[c4 * 32 + u].off = ((((c4 + ea[u]) & 3) * S.sw) + S.wlo + eb[u]) * 8;
+      const int slot0 = ((c4 + ea[u]) & 3) * S.sw, q = S.wlo + eb[u];
+      if (with_values) {
+        // spmv_sweep_kernel keeps a slab de-interleaved (even window entries in the first half, odd in the second, see
+        // write_slab): off = where the lane finds the operand of its first row, off1 = of its second row
+        const int half = S.sw / 2;
+        E[c4 * 32 + u].off = (q & 1) ? (slot0 + half + (q - 1) / 2) * 8 : (slot0 + q / 2) * 8;
+        E[c4 * 32 + u].off1 = (q & 1) ? (slot0 + (q + 1) / 2) * 8 : (slot0 + half + q / 2) * 8;
+      } else {
+        E[c4 * 32 + u].off = (slot0 + q) * 8;   // spmv_vsweep_kernel: window entries in order
+      }
       E[c4 * 32 + u].v = ev[u];
     }
   MK_HIP(hipMemcpyAsync(A->etab, E, sizeof(E), hipMemcpyHostToDevice, ctx().stream));
@@ -1182,8 +1191,13 @@ __global__ __launch_bounds__(T, T == 512 ? 2 : 1) void spmv_sweep_kernel(
         if (MODE == 5) regr[i] = MK_SWEEP_LDW(reinterpret_cast<const d2_t *>(reinterpret_cast<const char *>(rhs) + ((unsigned)g << 3)));
       }
     };
+    // A slab is stored de-interleaved: window entry e at [e / 2] of the first half (e even) or of the second half (e odd).
+    // A lane owns rows g, g + 1 and reads x[g + o], x[g + 1 + o] per entry: one from each half, and across the wave both
+    // reads are 64 consecutive doubles (entries in order: the two reads were 16 bytes apart from lane to lane, a 2-way bank
+    // conflict on every one of the 2 x 27 reads of a 27-point row, which bounds that kernel).
+    const int half = sw >> 1;
     auto write_slab = [&](int slot, int j, const d2_t(&reg)[NL], const d2_t(&regr)[NLR]) {
-      double *dst = ring + slot * sw + lr;
+      double *dst = ring + slot * sw + tid;
 #pragma unroll
       for (int i = 0; i < NL; i++) {
         const int wi = lr + i * 2 * T;   // position in the window
@@ -1202,7 +1216,8 @@ __global__ __launch_bounds__(T, T == 512 ? 2 : 1) void spmv_sweep_kernel(
               else if (g < nr) *reinterpret_cast<double *>(reinterpret_cast<char *>(y) + ((unsigned)g << 3)) = v.x;
             }
           }
-          *reinterpret_cast<d2_t *>(dst + i * 2 * T) = v;
+          dst[i * T] = v.x;
+          dst[i * T + half] = v.y;
         }
       }
     };
@@ -1259,7 +1274,7 @@ __global__ __launch_bounds__(T, T == 512 ? 2 : 1) void spmv_sweep_kernel(
         const bool two = g + 1 < nr;
         const unsigned mA = smask[id0 & 0xffffu];
         const unsigned mB = two ? smask[min(id0 >> 16, (unsigned)npat - 1u)] : 0u;
-        const char *wl = reinterpret_cast<const char *>(ring) + lr * 8;
+        const char *wl = reinterpret_cast<const char *>(ring) + tid * 8;
         double s0 = 0.0, s1 = 0.0;
         for (int u0 = 0; u0 < S.len; u0 += 8) {
           // Eight entries per batch by two 64-byte scalar loads (scalar cache).  The table is stored once per
@@ -1267,13 +1282,16 @@ __global__ __launch_bounds__(T, T == 512 ? 2 : 1) void spmv_sweep_kernel(
           // re-load it per step instead of keeping all 32 entries in SGPRs for the whole kernel (it did, and
           // spilled them: 487 v_readlane per step).  Branch-free: a row takes entry u iff bit u of its mask
           // is set (padding entries have no bit in any mask); the sum is SELECTED, not multiplied by 0/1.
+          // (A separate multiply-add chain without the selects for waves whose rows all hold the whole pattern was
+          // measured: 27-point CG 0.351 -> 0.345 ms per iteration, 7-point 1.517 -> 1.530: not kept.)
           typedef int i16_t __attribute__((ext_vector_type(16)));
           const i16_t *eb = reinterpret_cast<const i16_t *>(etab + jb * 32 + u0);
           const i16_t b0 = eb[0], b1 = eb[1];
-          int off[8];
+          int off[8], off1[8];
           double vv[8];
 #define MK_ENT(U, B, Q)                                                                                   \
   off[U] = B[4 * Q];                                                                                      \
+  off1[U] = B[4 * Q + 1];                                                                                 \
   vv[U] = __longlong_as_double((long long)(((unsigned long long)(unsigned)B[4 * Q + 3] << 32) | (unsigned)B[4 * Q + 2]));
           MK_ENT(0, b0, 0) MK_ENT(1, b0, 1) MK_ENT(2, b0, 2) MK_ENT(3, b0, 3)
           MK_ENT(4, b1, 0) MK_ENT(5, b1, 1) MK_ENT(6, b1, 2) MK_ENT(7, b1, 3)
@@ -1281,9 +1299,8 @@ __global__ __launch_bounds__(T, T == 512 ? 2 : 1) void spmv_sweep_kernel(
           double p0[8], p1[8];
 #pragma unroll
           for (int u = 0; u < 8; u++) {
-            const double *w = reinterpret_cast<const double *>(wl + off[u]);
-            p0[u] = w[0];
-            p1[u] = w[1];
+            p0[u] = *reinterpret_cast<const double *>(wl + off[u]);
+            p1[u] = *reinterpret_cast<const double *>(wl + off1[u]);
           }
           const unsigned ka = mA >> u0, kb = mB >> u0;
 #pragma unroll
@@ -1298,8 +1315,8 @@ __global__ __launch_bounds__(T, T == 512 ? 2 : 1) void spmv_sweep_kernel(
           out.x = (beta == 0.0) ? alpha * s0 : alpha * s0 + beta * ax0.x;
           out.y = (beta == 0.0) ? alpha * s1 : alpha * s1 + beta * ax0.y;
         } else {
-          const double *wc = reinterpret_cast<const double *>(wl) + jb * sw + S.wlo;   // x[g], x[g+1]
-          const double xa = wc[0], xb = wc[1];
+          const double *wc = reinterpret_cast<const double *>(wl) + jb * sw + (S.wlo >> 1);   // x[g], x[g+1]
+          const double xa = wc[0], xb = wc[half];
           if (MODE == 2) {
             const double ra = (ax0.x - ex0.x) - s0, rb = (ax0.y - ex0.y) - s1;
             const double da = (S.diag >= 0 && ((mA >> S.diag) & 1u)) ? dvb : 0.0;
