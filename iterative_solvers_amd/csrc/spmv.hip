@@ -1089,6 +1089,14 @@ template <bool NT, typename V>
 __device__ __forceinline__ V sweep_ld(const V *ptr) {
   return NT ? __builtin_nontemporal_load(ptr) : *ptr;
 }
+// m = 0 or -1: t where m is set, s elsewhere (v_bfi_b32 on both halves)
+__device__ __forceinline__ double bit_select(int m, double t, double s) {
+  const unsigned long long tb = (unsigned long long)__double_as_longlong(t), sb = (unsigned long long)__double_as_longlong(s);
+  unsigned lo, hi;
+  asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(lo) : "v"(m), "v"((unsigned)tb), "v"((unsigned)sb));
+  asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(hi) : "v"(m), "v"((unsigned)(tb >> 32)), "v"((unsigned)(sb >> 32)));
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
 #define MK_SWEEP_ST(ptr, v) sweep_st<NT>((ptr), (v))
 #define MK_SWEEP_LD(ptr) sweep_ld<NT>(ptr)
 #define MK_SWEEP_LDW(ptr) (*(ptr))
@@ -1302,12 +1310,20 @@ __global__ __launch_bounds__(T, T == 512 ? 2 : 1) void spmv_sweep_kernel(
             p0[u] = *reinterpret_cast<const double *>(wl + off[u]);
             p1[u] = *reinterpret_cast<const double *>(wl + off1[u]);
           }
-          const unsigned ka = mA >> u0, kb = mB >> u0;
+          // 27-point rows are bound by vector issue (91 % of the slots), so the select is spelled out: m = bit u of the
+          // row's mask spread over a register (v_bfe_i32), then one v_bfi_b32 per half, s = (m & t) | (~m & s); and the
+          // three-operand v_fma_f64 leaves s alone.  10 vector instructions per entry and row pair where the compiler's
+          // and / compare / v_cndmask x 2 / v_mov_b64 (its fmac overwrites the sum) took 16.
+          const int ka = (int)(mA >> u0), kb = (int)(mB >> u0);
+          __builtin_amdgcn_sched_barrier(0);   // all sixteen reads are in flight before the first multiply-add waits
 #pragma unroll
           for (int u = 0; u < 8; u++) {
-            const double t0 = s0 + vv[u] * p0[u], t1 = s1 + vv[u] * p1[u];
-            s0 = ((ka >> u) & 1u) ? t0 : s0;
-            s1 = ((kb >> u) & 1u) ? t1 : s1;
+            double t0, t1;
+            asm("v_fma_f64 %0, %1, %2, %3" : "=v"(t0) : "s"(vv[u]), "v"(p0[u]), "v"(s0));
+            asm("v_fma_f64 %0, %1, %2, %3" : "=v"(t1) : "s"(vv[u]), "v"(p1[u]), "v"(s1));
+            const int ma = __builtin_amdgcn_sbfe(ka, u, 1), mb = __builtin_amdgcn_sbfe(kb, u, 1);
+            s0 = bit_select(ma, t0, s0);
+            s1 = bit_select(mb, t1, s1);
           }
         }
         d2_t out;
