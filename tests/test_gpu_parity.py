@@ -250,7 +250,7 @@ def test_spmv_sweep_kernel(kind, dims):
     assert np.array_equal(res[mk.SPMV_SWEEP][3], res[mk.SPMV_PATTERN][3])      # Jacobi sweeps: same bits per row
 
 
-@pytest.mark.parametrize("n,hb", [(1, 1), (2, 1), (7, 3), (511, 2), (513, 3), (1025, 1), (100001, 3), (4099, 15)])
+@pytest.mark.parametrize("n,hb", [(1, 1), (2, 1), (7, 3), (511, 2), (513, 3), (1025, 1), (100001, 3), (4099, 15), (300003, 3)])   # 300003: planes of 64 chunks, ragged last plane
 def test_spmv_pattern_and_sweep_ragged_sizes(n, hb):
     """odd row counts (a lane's second row missing), fewer rows than one chunk, rows shorter than the band at
     both ends: pattern and sweep kernels against the serial reference, bit for bit; then whole solves"""
@@ -404,7 +404,7 @@ def test_spmv_vsweep_device_generated_matches_oracle_generator():
     assert np.array_equal(bci, ci[rp[lo]:rp[hi]]) and np.array_equal(bv.view(np.uint64), v[rp[lo]:rp[hi]].view(np.uint64))
 
 
-@pytest.mark.parametrize("n,hb", [(7, 3), (511, 2), (513, 3), (1025, 1), (100001, 3), (70000, 2)])
+@pytest.mark.parametrize("n,hb", [(7, 3), (511, 2), (513, 3), (1025, 1), (100001, 3), (70000, 2), (262921, 3)])
 def test_spmv_vsweep_ragged_banded(n, hb):
     """banded matrices with random values (the contiguous sweep mode): odd row counts, fewer rows than a chunk, short rows
     at both ends"""
