@@ -123,6 +123,10 @@ struct LocalWorld {
   std::vector<mk_comm *> comms;
   std::vector<mk_dist_matrix *> mats;   // registered by rank
   double **d_ptrs = nullptr;            // device array of nranks pointers (all-reduce emulation)
+  // the local world's stand-in for the communication stream: halo copies and the off-rank products of the fused CG step
+  // run here, beside the diag sweeps on the main stream, exactly as they do on the RCCL communication stream
+  hipStream_t side = nullptr;
+  hipEvent_t ev_ready = nullptr, ev_done = nullptr;
 };
 
 // ------------------------------------------------------------------------------ kernels
@@ -227,13 +231,31 @@ __global__ void pack_new_p_kernel(int n, const int *__restrict__ idx, HaloFuse f
 // per-block partial of sum_i (contribution_i * xlocal[rows[i]]) goes to slab component 0
 // (component 1 gets 0) so that <A p, p> can be completed after the diag pass.
 // COMPACT: y is a vector over the compressed list of rows (t[i]) instead of over the local rows (y[rows[i]])
-template <int G, bool DOT, bool SET, bool COMPACT = false>
+// FUSE (fused CG step from its second iteration on, the kernel runs BESIDE the sweep that forms p' = z + beta p): the
+// local operand of the dot is not read from xlocal (the sweep is writing it) but formed from r and the old p with
+// K3's own tests and the sweep's own expression, as pack_new_p_kernel does for the send rows.
+template <int G, bool DOT, bool SET, bool COMPACT = false, bool FUSE = false>
 __global__ __launch_bounds__(256) void offd_spmv_kernel(int nrows, const int *__restrict__ rowptr, const int *__restrict__ col,
                                                         const double *__restrict__ val, const int *__restrict__ rows,
                                                         const double *__restrict__ xghost, const double *__restrict__ xlocal,
                                                         double *__restrict__ y, double alpha, double *__restrict__ slab,
-                                                        const int *__restrict__ done) {
+                                                        const int *__restrict__ done, HaloFuse f) {
   if (done != nullptr && *done != 0) return;
+  double beta = 0.0;
+  if (FUSE) {
+    const PcgState *st = f.st;
+    const double gamma_new = f.buf3[0];
+    const double i_prod = (f.flags & 1) ? f.buf3[1] : f.buf3[0];
+    const double xx = f.buf3[2];
+    bool conv = (i_prod / st->bi_prod < st->eps);
+    if (conv && (f.flags & 2) && i_prod > 0.0) {
+      const double ratio = st->alpha * st->alpha * st->pp / xx;
+      if (ratio >= st->eps) conv = false;
+    }
+    const bool tiny_gamma = (gamma_new < DBL_MIN) && (-gamma_new < DBL_MIN);
+    if (conv || tiny_gamma) return;
+    beta = gamma_new / st->gamma_old;
+  }
   constexpr int ROWS = 256 / G;
   const int g = threadIdx.x % G, rl = threadIdx.x / G;
   double acc = 0.0;
@@ -249,7 +271,17 @@ __global__ __launch_bounds__(256) void offd_spmv_kernel(int nrows, const int *__
       if (COMPACT) y[i] = add;
       else if (SET) y[r] = add;
       else y[r] += add;
-      if (DOT) acc += add * xlocal[r];
+      if (DOT) {
+        double xl;
+        if (FUSE) {
+          double z = f.r[r];
+          z *= f.zscale;
+          xl = beta * f.p_old[r] + z;
+        } else {
+          xl = xlocal[r];
+        }
+        acc += add * xl;
+      }
     }
   }
   if (DOT) {
@@ -406,16 +438,23 @@ static int halo_exchange(int R, mk_dist_matrix **A, double **v, bool overlap, co
   Context &c = ctx();
   if (A[0]->comm == nullptr) return MK_OK;
   if (A[0]->comm->local) {
+    LocalWorld *W = A[0]->comm->world;
+    hipStream_t ls = overlap ? W->side : c.stream;
+    if (overlap) {
+      MK_HIP(hipEventRecord(W->ev_ready, c.stream));
+      MK_HIP(hipStreamWaitEvent(ls, W->ev_ready, 0));
+    }
     for (int r = 0; r < R; r++)
       if (A[r]->n_send) {
-        if (fuse && fuse[r].st) hipLaunchKernelGGL(pack_new_p_kernel, dim3(grid1(A[r]->n_send, 1024)), dim3(256), 0, c.stream, A[r]->n_send, A[r]->send_idx, fuse[r], A[r]->sendbuf);
-        else hipLaunchKernelGGL(pack_kernel, dim3(grid1(A[r]->n_send, 1024)), dim3(256), 0, c.stream, A[r]->n_send, A[r]->send_idx, v[r], A[r]->sendbuf);
+        if (fuse && fuse[r].st) hipLaunchKernelGGL(pack_new_p_kernel, dim3(grid1(A[r]->n_send, 1024)), dim3(256), 0, ls, A[r]->n_send, A[r]->send_idx, fuse[r], A[r]->sendbuf);
+        else hipLaunchKernelGGL(pack_kernel, dim3(grid1(A[r]->n_send, 1024)), dim3(256), 0, ls, A[r]->n_send, A[r]->send_idx, v[r], A[r]->sendbuf);
       }
     for (int r = 0; r < R; r++)
       for (int q = 0; q < R; q++)
         if (A[r]->recv_cnt[q])
           MK_HIP(hipMemcpyAsync(v[r] + A[r]->n_local + A[r]->recv_off[q], A[q]->sendbuf + A[q]->send_off[r],
-                                sizeof(double) * A[r]->recv_cnt[q], hipMemcpyDeviceToDevice, c.stream));
+                                sizeof(double) * A[r]->recv_cnt[q], hipMemcpyDeviceToDevice, ls));
+    if (overlap) MK_HIP(hipEventRecord(W->ev_done, ls));
     return MK_OK;
   }
   mk_dist_matrix *D = A[0];
@@ -440,8 +479,22 @@ static int halo_exchange(int R, mk_dist_matrix **A, double **v, bool overlap, co
 }
 
 static int halo_wait(mk_dist_matrix *D, bool overlap) {
-  if (D->comm == nullptr || D->comm->local || !overlap) return MK_OK;
-  MK_HIP(hipStreamWaitEvent(ctx().stream, D->comm->ev_halo, 0));
+  if (D->comm == nullptr || !overlap) return MK_OK;
+  if (D->comm->local) MK_HIP(hipStreamWaitEvent(ctx().stream, D->comm->world->ev_done, 0));
+  else MK_HIP(hipStreamWaitEvent(ctx().stream, D->comm->ev_halo, 0));
+  return MK_OK;
+}
+
+// the stream the halo of this matrix arrives on, for work that is to run there behind the exchange; halo_mark() moves the
+// event halo_wait() waits for behind that work
+static hipStream_t halo_stream(const mk_dist_matrix *D) {
+  if (D->comm == nullptr) return ctx().stream;
+  return D->comm->local ? D->comm->world->side : D->comm->comm_stream;
+}
+static int halo_mark(mk_dist_matrix *D) {
+  if (D->comm == nullptr) return MK_OK;
+  if (D->comm->local) MK_HIP(hipEventRecord(D->comm->world->ev_done, D->comm->world->side));
+  else MK_HIP(hipEventRecord(D->comm->ev_halo, D->comm->comm_stream));
   return MK_OK;
 }
 
@@ -472,24 +525,28 @@ static int launch_offd(const mk_dist_matrix *D, const double *xext, double *y, d
   if (nblocks) *nblocks = blocks;
   if (D->n_offd_rows == 0 && !DOT) return MK_OK;
 #define MK_OFFD(GG) case GG: hipLaunchKernelGGL((offd_spmv_kernel<GG, DOT, SET>), dim3(blocks), dim3(256), 0, c.stream, D->n_offd_rows, \
-    D->offd.rowptr, D->offd.col, D->offd.val, D->offd_rows, xext + D->n_local, xext, y, alpha, slab, done); break;
+    D->offd.rowptr, D->offd.col, D->offd.val, D->offd_rows, xext + D->n_local, xext, y, alpha, slab, done, HaloFuse()); break;
   switch (G) { MK_OFFD(1) MK_OFFD(2) MK_OFFD(4) MK_OFFD(8) MK_OFFD(16) MK_OFFD(32) MK_OFFD(64) default: return fail(MK_ERR_INVALID, "offd lanes"); }
 #undef MK_OFFD
   MK_HIP(hipGetLastError());
   return MK_OK;
 }
 
-// t[i] = (offd x_ghost)[i] over the rows that touch ghosts, partial of <t, x_local> (fused row-block CG step)
+// t[i] = (offd x_ghost)[i] over the rows that touch ghosts, partial of <t, x_local> (fused row-block CG step).
+// stream: where the ghosts arrive (communication / side stream); fuse: the local operand is formed from r and the old p
 static int launch_offd_compact(const mk_dist_matrix *D, const double *xext, double *t, double *slab, const int *done, int *nblocks,
-                               int max_blocks) {
-  Context &c = ctx();
+                               int max_blocks, hipStream_t stream, const HaloFuse *fuse) {
   const int G = D->offd_lanes;
   const int rows_per_block = 256 / G;
   if (max_blocks < 1) return fail(MK_ERR_UNSUPPORTED, "row-block CG: the diag block's %d reduction partials leave no room for the off-rank product's", kSlabStride - max_blocks);
   int blocks = std::max(1, std::min((D->n_offd_rows + rows_per_block - 1) / rows_per_block, std::min(1024, max_blocks)));
   if (nblocks) *nblocks = blocks;
-#define MK_OFFD(GG) case GG: hipLaunchKernelGGL((offd_spmv_kernel<GG, true, true, true>), dim3(blocks), dim3(256), 0, c.stream, D->n_offd_rows, \
-    D->offd.rowptr, D->offd.col, D->offd.val, D->offd_rows, xext + D->n_local, xext, t, 1.0, slab, done); break;
+#define MK_OFFD(GG) case GG: \
+    if (fuse && fuse->st) hipLaunchKernelGGL((offd_spmv_kernel<GG, true, true, true, true>), dim3(blocks), dim3(256), 0, stream, D->n_offd_rows, \
+      D->offd.rowptr, D->offd.col, D->offd.val, D->offd_rows, xext + D->n_local, xext, t, 1.0, slab, done, *fuse); \
+    else hipLaunchKernelGGL((offd_spmv_kernel<GG, true, true, true, false>), dim3(blocks), dim3(256), 0, stream, D->n_offd_rows, \
+      D->offd.rowptr, D->offd.col, D->offd.val, D->offd_rows, xext + D->n_local, xext, t, 1.0, slab, done, HaloFuse()); \
+    break;
   switch (G) { MK_OFFD(1) MK_OFFD(2) MK_OFFD(4) MK_OFFD(8) MK_OFFD(16) MK_OFFD(32) MK_OFFD(64) default: return fail(MK_ERR_INVALID, "offd lanes"); }
 #undef MK_OFFD
   MK_HIP(hipGetLastError());
@@ -562,6 +619,9 @@ int mk_comm_create_local(int nranks, mk_comm **comms) {
   W->nranks = nranks;
   W->mats.assign(nranks, nullptr);
   MK_TRY(dev_alloc(&W->d_ptrs, (size_t)nranks));
+  MK_HIP(hipStreamCreateWithFlags(&W->side, hipStreamNonBlocking));
+  MK_HIP(hipEventCreateWithFlags(&W->ev_ready, hipEventDisableTiming));
+  MK_HIP(hipEventCreateWithFlags(&W->ev_done, hipEventDisableTiming));
   for (int r = 0; r < nranks; r++) {
     mk_comm *cm = new mk_comm();
     cm->nranks = nranks; cm->rank = r; cm->local = true; cm->world = W;
@@ -639,7 +699,13 @@ int mk_comm_destroy(mk_comm *cm) {
     W->comms[cm->rank] = nullptr;
     bool last = true;
     for (mk_comm *o : W->comms) if (o) last = false;
-    if (last) { dev_free(W->d_ptrs); delete W; }
+    if (last) {
+      dev_free(W->d_ptrs);
+      if (W->ev_ready) (void)hipEventDestroy(W->ev_ready);
+      if (W->ev_done) (void)hipEventDestroy(W->ev_done);
+      if (W->side) (void)hipStreamDestroy(W->side);
+      delete W;
+    }
   } else {
     if (cm->coll) (void)g_rccl.CommDestroy(cm->coll);
     if (cm->p2p) (void)g_rccl.CommDestroy(cm->p2p);
@@ -786,7 +852,6 @@ int mk_dist_pcg_solve(int R, mk_pcg **solvers, mk_dist_matrix **A, mk_vector **b
     if (solvers[r]->max_iter != S0->max_iter || solvers[r]->tol != S0->tol || solvers[r]->precond != S0->precond)
       return fail(MK_ERR_INVALID, "mk_dist_pcg_solve: ranks disagree on solver settings");
   }
-  const bool rccl = A[0]->comm != nullptr && !A[0]->comm->local;
   const bool want_norms = S0->logging > 0 || S0->print_level > 0;
   std::vector<DistWork> W(R);
   std::vector<double *> pv(R), xv(R), bufs(R), pold(R, nullptr);
@@ -795,6 +860,7 @@ int mk_dist_pcg_solve(int R, mk_pcg **solvers, mk_dist_matrix **A, mk_vector **b
   std::vector<HaloFuse> hf(R);
   static const int no_fused = getenv("MK_NO_FUSED_CG") ? atoi(getenv("MK_NO_FUSED_CG")) : 0;
   static const int no_pfuse = getenv("MK_NO_FUSED_K3") ? atoi(getenv("MK_NO_FUSED_K3")) : 0;
+  static const int no_beside = getenv("MK_NO_OFFD_OVERLAP") ? atoi(getenv("MK_NO_OFFD_OVERLAP")) : 0;   // A/B: off-rank product after the sweep
   int rc = MK_OK;
   auto cleanup = [&]() { (void)hipDeviceSynchronize(); for (auto &w : W) w.release(); };
 #define MK_D(expr) do { rc = (expr); if (rc != MK_OK) { cleanup(); return rc; } } while (0)
@@ -869,7 +935,7 @@ int mk_dist_pcg_solve(int R, mk_pcg **solvers, mk_dist_matrix **A, mk_vector **b
         pv[r] = (pv[r] == W[r].p) ? W[r].p2 : W[r].p;
       }
     }
-    MK_D(halo_exchange(R, A, pv.data(), rccl, hf.data()));                       // on the communication stream over RCCL
+    MK_D(halo_exchange(R, A, pv.data(), true, hf.data()));   // on the communication stream (local world: its side stream)
     for (int r = 0; r < R; r++) {                                                 // K1a: diag block, overlaps the halo
       if (pfuse[r] && it > 0)
         MK_D(launch_sweep_cg_pdots(&A[r]->diag, W[r].r, pold[r], pv[r], zs[r], W[r].buf + 4, 1, 1, W[r].slab1, W[r].state, two_norm,
@@ -877,12 +943,23 @@ int mk_dist_pcg_solve(int R, mk_pcg **solvers, mk_dist_matrix **A, mk_vector **b
       else if (fusedv[r]) MK_D(launch_sweep_cg_dots(&A[r]->diag, pv[r], W[r].slab1, W[r].state, &nb1[r]));
       else MK_D(launch_spmv_dot(&A[r]->diag, pv[r], W[r].s, W[r].slab1, &W[r].state->done, &nb1[r]));
     }
-    for (int r = 0; r < R; r++) {                                                 // K1b: offd block once the ghosts are in
-      MK_D(halo_wait(A[r], rccl));
-      // the off-rank partials sit behind the diag kernel's in the same slab: nb1 + nb2 <= kSlabStride, or component 0
-      // of the off-rank part would run into component 1 of the diag part
-      if (fusedv[r]) MK_D(launch_offd_compact(A[r], pv[r], W[r].t, W[r].slab1 + nb1[r], &W[r].state->done, &nb2[r], kSlabStride - nb1[r]));
-      else MK_D(launch_offd<true>(A[r], pv[r], W[r].s, 1.0, W[r].slab1 + nb1[r], &W[r].state->done, &nb2[r], kSlabStride - nb1[r]));
+    // K1b, fused ranks: the off-rank product into the compact buffer t runs on the stream the ghosts arrive on, BESIDE the
+    // diag sweep (it writes t and its own partials only; where the sweep is still forming p' the kernel forms the local
+    // operand of its dot itself).  The off-rank partials sit behind the diag kernel's in the same slab: nb1 + nb2 <=
+    // kSlabStride, or component 0 of the off-rank part would run into component 1 of the diag part.
+    bool beside = false;
+    for (int r = 0; r < R; r++)
+      if (fusedv[r] && !no_beside) {
+        const HaloFuse *f = (pfuse[r] && it > 0) ? &hf[r] : nullptr;
+        MK_D(launch_offd_compact(A[r], pv[r], W[r].t, W[r].slab1 + nb1[r], &W[r].state->done, &nb2[r], kSlabStride - nb1[r], halo_stream(A[r]), f));
+        beside = true;
+      }
+    if (beside) MK_D(halo_mark(A[0]));
+    for (int r = 0; r < R; r++) {                                                 // the rest once the ghosts are in
+      MK_D(halo_wait(A[r], true));
+      if (fusedv[r] && no_beside)
+        MK_D(launch_offd_compact(A[r], pv[r], W[r].t, W[r].slab1 + nb1[r], &W[r].state->done, &nb2[r], kSlabStride - nb1[r], c.stream, nullptr));
+      else if (!fusedv[r]) MK_D(launch_offd<true>(A[r], pv[r], W[r].s, 1.0, W[r].slab1 + nb1[r], &W[r].state->done, &nb2[r], kSlabStride - nb1[r]));
       hipLaunchKernelGGL((finalize_slab_kernel<2>), dim3(1), dim3(kVecThreads), 0, c.stream, W[r].slab1, nb1[r] + nb2[r], W[r].buf);
     }
     MK_D(all_reduce(R, A, bufs.data(), 2));                                       // <s,p>, <p,p>
