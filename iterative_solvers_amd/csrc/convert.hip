@@ -442,8 +442,12 @@ int device_coo_to_csr(mk_coo *coo, mk_matrix *A, int **sorted_rows_out) {
     size_t off = 0;
     auto carve = [&](size_t bytes) { const size_t o = off; off += (bytes + 511) & ~(size_t)255; return o; };   // >= 256 B slack each
     const size_t o_keys_f = carve((size_t)nnz * 4);
-    const size_t o_keys_s = passes > 1 ? carve((size_t)nnz * 4) : 0, o_cols_s = passes > 1 ? carve((size_t)nnz * 4) : 0;
-    const size_t o_vals_s = passes > 1 ? carve((size_t)nnz * 8) : 0;
+    // S is first written by pass 1 when the number of passes is odd: the caller's own arrays (pass 0 has read them by then)
+    // serve, and the scratch block shrinks from 20 to 4 bytes per entry
+    const bool s_is_input = (passes % 2 == 1);
+    const bool s_in_scratch = passes > 1 && !s_is_input;
+    const size_t o_keys_s = s_in_scratch ? carve((size_t)nnz * 4) : 0, o_cols_s = s_in_scratch ? carve((size_t)nnz * 4) : 0;
+    const size_t o_vals_s = s_in_scratch ? carve((size_t)nnz * 8) : 0;
     const size_t o_table = carve(ntab * 4), o_ws = carve(scan_workspace_count(ntab) * 4);
     MK_TRY(dev_alloc(&scratch, off));
     int *cols_f = nullptr;
@@ -452,8 +456,9 @@ int device_coo_to_csr(mk_coo *coo, mk_matrix *A, int **sorted_rows_out) {
     if (rc == MK_OK) rc = dev_alloc(&vals_f, (size_t)nnz);
     if (rc != MK_OK) { dev_free(scratch); dev_free(cols_f); return rc; }
     int *keys_f = reinterpret_cast<int *>(scratch + o_keys_f);
-    int *keys_s = reinterpret_cast<int *>(scratch + o_keys_s), *cols_s = reinterpret_cast<int *>(scratch + o_cols_s);
-    double *vals_s = reinterpret_cast<double *>(scratch + o_vals_s);
+    int *keys_s = s_is_input ? keys : reinterpret_cast<int *>(scratch + o_keys_s);
+    int *cols_s = s_is_input ? cols : reinterpret_cast<int *>(scratch + o_cols_s);
+    double *vals_s = s_is_input ? vals : reinterpret_cast<double *>(scratch + o_vals_s);
     uint32_t *table = reinterpret_cast<uint32_t *>(scratch + o_table), *ws = reinterpret_cast<uint32_t *>(scratch + o_ws);
     MK_TR("alloc sort buffers");
     spent.push_back(keys);
