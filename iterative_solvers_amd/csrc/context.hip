@@ -1,4 +1,7 @@
 // context.hip -- library life cycle, error text, vectors, timers, host-side partitioner.
+#include <map>
+#include <mutex>
+#include <unordered_map>
 #include "mk_internal.h"
 
 #include <algorithm>
@@ -20,6 +23,75 @@ int fail(int code, const char *fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
   return code;
+}
+
+// ------------------------------------------------------------------ caching allocator (see mk_internal.h)
+namespace {
+struct AllocCache {
+  std::mutex mu;
+  std::unordered_map<void *, size_t> live;        // every block handed out -> its size
+  std::multimap<size_t, void *> idle;             // blocks waiting for reuse, by size
+  size_t idle_bytes = 0, cap = 0;
+  bool enabled = false;
+};
+AllocCache g_cache;
+constexpr size_t kCacheMinBlock = (size_t)1 << 20;
+}  // namespace
+
+void cache_release_all() {
+  std::lock_guard<std::mutex> lk(g_cache.mu);
+  for (auto &b : g_cache.idle) (void)hipFree(b.second);
+  g_cache.idle.clear();
+  g_cache.idle_bytes = 0;
+}
+
+void *cached_alloc(size_t bytes) {
+  bytes = (bytes + 255) & ~(size_t)255;
+  void *p = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_cache.mu);
+    if (g_cache.enabled && bytes >= kCacheMinBlock) {
+      auto it = g_cache.idle.lower_bound(bytes);
+      if (it != g_cache.idle.end() && it->first <= bytes + bytes / 8) {
+        p = it->second;
+        g_cache.idle_bytes -= it->first;
+        g_cache.live[p] = it->first;
+        g_cache.idle.erase(it);
+        return p;
+      }
+    }
+  }
+  hipError_t e = hipMalloc(&p, bytes);
+  if (e != hipSuccess) {   // give back what the cache holds and try once more
+    (void)hipGetLastError();
+    cache_release_all();
+    e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      return nullptr;
+    }
+  }
+  std::lock_guard<std::mutex> lk(g_cache.mu);
+  g_cache.live[p] = bytes;
+  return p;
+}
+
+void cached_free(void *p) {
+  size_t bytes = 0;
+  {
+    std::lock_guard<std::mutex> lk(g_cache.mu);
+    auto it = g_cache.live.find(p);
+    if (it != g_cache.live.end()) {
+      bytes = it->second;
+      g_cache.live.erase(it);
+    }
+    if (g_cache.enabled && bytes >= kCacheMinBlock && g_cache.idle_bytes + bytes <= g_cache.cap) {
+      g_cache.idle.emplace(bytes, p);
+      g_cache.idle_bytes += bytes;
+      return;
+    }
+  }
+  (void)hipFree(p);
 }
 
 Context &ctx() {
@@ -64,6 +136,14 @@ int mk_init(int device_id) {
   MK_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
   MK_HIP(hipEventCreate(&c.ev0));
   MK_HIP(hipEventCreate(&c.ev1));
+  {
+    size_t free_b = 0, total_b = 0;
+    MK_HIP(hipMemGetInfo(&free_b, &total_b));
+    const char *cap_mb = getenv("MK_ALLOC_CACHE_MB");
+    std::lock_guard<std::mutex> lk(g_cache.mu);
+    g_cache.cap = cap_mb ? (size_t)atoll(cap_mb) << 20 : total_b / 4;
+    g_cache.enabled = !(getenv("MK_NO_ALLOC_CACHE") && atoi(getenv("MK_NO_ALLOC_CACHE")));
+  }
   c.pinned_bytes = 1 << 16;
   MK_HIP(hipHostMalloc(&c.pinned, c.pinned_bytes, hipHostMallocDefault));
   MK_TRY(dev_alloc(&c.slab, (size_t)kMaxParts * kSlabStride));
@@ -82,6 +162,11 @@ int mk_finalize(void) {
   (void)hipHostFree(c.pinned);
   dev_free(c.slab);
   dev_free(c.scalars);
+  {
+    std::lock_guard<std::mutex> lk(g_cache.mu);
+    g_cache.enabled = false;   // objects destroyed after this point free their memory directly
+  }
+  cache_release_all();
   (void)hipStreamDestroy(c.stream);
   c = Context();
   return MK_OK;
