@@ -80,6 +80,11 @@ void *mk_get_stream(void);
  * (the reference samples `nvidia-smi -i <id>`, cpower.h:124-130) */
 int mk_get_device_pci_bus_id(int device_id, char *out, int capacity);
 int mk_synchronize(void);
+/* Device memory the library holds (no reference counterpart: the reference leaves memory to HYPRE).  Freed arrays of 1 MB and
+ * more stay in a free list for reuse (hipFree costs 0.2 ms a call): in_use = bytes inside live objects, idle = bytes waiting
+ * in the list.  mk_memory_trim() gives the idle blocks back to the driver (a long-running host does this after set-up). */
+int mk_memory_info(long long *in_use_bytes, long long *idle_bytes);
+int mk_memory_trim(void);
 /* HIP-event timers on that stream: start, stop, then elapsed (milliseconds, synchronises) */
 int mk_timer_start(void);
 int mk_timer_stop(float *elapsed_ms);

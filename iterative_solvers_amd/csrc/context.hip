@@ -184,6 +184,23 @@ int mk_get_device_pci_bus_id(int device_id, char *out, int capacity) {
   return MK_OK;
 }
 
+int mk_memory_info(long long *in_use_bytes, long long *idle_bytes) {
+  MK_REQUIRE_INIT();
+  std::lock_guard<std::mutex> lk(g_cache.mu);
+  long long live = 0;
+  for (auto &b : g_cache.live) live += (long long)b.second;
+  if (in_use_bytes) *in_use_bytes = live;
+  if (idle_bytes) *idle_bytes = (long long)g_cache.idle_bytes;
+  return MK_OK;
+}
+
+int mk_memory_trim(void) {
+  MK_REQUIRE_INIT();
+  MK_HIP(hipStreamSynchronize(ctx().stream));
+  cache_release_all();
+  return MK_OK;
+}
+
 int mk_synchronize(void) {
   MK_REQUIRE_INIT();
   MK_HIP(hipStreamSynchronize(ctx().stream));

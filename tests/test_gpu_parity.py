@@ -1131,3 +1131,30 @@ def test_full_size_config2_properties():
     A.spmv(x, y)
     true_rel = np.linalg.norm(1.0 - y.get()) / np.sqrt(n)
     assert np.isclose(true_rel, res["rel_res_norm"], rtol=1e-6)
+
+
+def test_allocator_keeps_and_reuses_large_blocks():
+    """freed device arrays of 1 MB and more wait in the library's free list and serve the next request of their size;
+    mk_memory_trim() returns them to the driver (include/mk_krylov.h mk_memory_info / mk_memory_trim)"""
+    mk.init(0)
+    mk.memory_trim()
+    n = 3 * (1 << 20)                                   # 24 MB of doubles
+    live0, idle0 = mk.memory_info()
+    assert idle0 == 0
+    v = mk.Vector(n, fill=1.5)
+    live1, idle1 = mk.memory_info()
+    assert live1 - live0 >= 8 * n and idle1 == 0
+    del v
+    live2, idle2 = mk.memory_info()
+    assert live2 == live0 and idle2 >= 8 * n            # kept, not freed
+    w = mk.Vector(n, fill=2.5)                          # same size: the kept block is handed out again
+    live3, idle3 = mk.memory_info()
+    assert idle3 == 0 and live3 == live1
+    assert np.all(w.get() == 2.5)
+    small = mk.Vector(1000, fill=1.0)                   # below 1 MB: never kept
+    del small
+    assert mk.memory_info()[1] == 0
+    del w
+    assert mk.memory_info()[1] >= 8 * n
+    mk.memory_trim()
+    assert mk.memory_info() == (live0, 0)
