@@ -1015,6 +1015,11 @@ int mk_dist_pcg_solve(int R, mk_pcg **solvers, mk_dist_matrix **A, mk_vector **b
       solvers[r]->norms_cap = S0->max_iter + 1;
       W[r].norms = nullptr;
     }
+    if (solvers[r]->print_level > 1 && solvers[r]->norms && !zero_rhs && hst[0].iter <= S0->max_iter) {
+      std::vector<double> h((size_t)hst[0].iter + 1);
+      if (hipMemcpy(h.data(), solvers[r]->norms, sizeof(double) * h.size(), hipMemcpyDeviceToHost) == hipSuccess)
+        print_pcg_table(two_norm, h.data(), hst[0].iter, sqrt(hst[0].bi_prod));
+    }
   }
   cleanup();
 #undef MK_D

@@ -224,10 +224,10 @@ int mk_pcg_solve(mk_pcg *S, const mk_matrix *A, const mk_vector *b, mk_vector *x
           if (hipEventElapsedTime(&ms, S->tev[i * nslots + k], S->tev[i * nslots + k + 1]) == hipSuccess) { S->kt_ms[k] += ms; S->kt_launches[k]++; }
         }
   }
-  if (S->print_level > 1) {
-    // same three facts HYPRE's print level reports per solve; per-iteration table omitted
-    printf("PCG: %lld iterations, relative residual %e%s\n", S->iterations, S->rel_res_norm,
-           S->converged ? "" : " (not converged)");
+  if (S->print_level > 1 && S->norms && S->iterations >= 0 && S->iterations < S->norms_cap) {
+    std::vector<double> h((size_t)S->iterations + 1);
+    MK_HIP(hipMemcpy(h.data(), S->norms, sizeof(double) * h.size(), hipMemcpyDeviceToHost));
+    print_pcg_table(S->two_norm, h.data(), S->iterations, sqrt(hst[0].bi_prod));
   }
   return MK_OK;
 }

@@ -3,6 +3,7 @@
 #pragma once
 #include <cfloat>
 #include <cmath>
+#include <cstdio>
 
 #include "mk_internal.h"
 
@@ -209,6 +210,21 @@ __global__ __launch_bounds__(kVecThreads) void pcg_update_p_kernel(int64_t n, co
     const double zi = PRECOND ? r[i] * dinv[i] : r[i];
     p[i] = beta * p[i] + zi;
   }
+}
+
+// hypre_PCGSolve's per-iteration table at print level 2 and above (the reference driver's default, solvers.c:742 with
+// prnt_info = 2), written from the residual history after the solve: rel[i] = ||r_i|| / ||b|| in the norm the solve uses
+// (two_norm: l2, else the C-norm), bnorm = ||b|| in that norm.  Layout and formats as in the published hypre pcg.c.
+static inline void print_pcg_table(int two_norm, const double *rel, long long iterations, double bnorm) {
+  printf("\n\n");
+  if (two_norm) printf("Iters       ||r||_2     conv.rate  ||r||_2/||b||_2\n");
+  else printf("Iters       ||r||_C     conv.rate  ||r||_C/||b||_C\n");
+  printf("-----    ------------    ---------  ------------ \n");
+  for (long long i = 1; i <= iterations; i++) {
+    const double ni = rel[i] * bnorm, np = rel[i - 1] * bnorm;
+    printf("% 5d    %e    %f    %e\n", (int)i, ni, ni / np, rel[i]);
+  }
+  printf("\n\n");
 }
 
 static __global__ void copy_kernel(double *__restrict__ dst, const double *__restrict__ src, int64_t n) {

@@ -262,6 +262,31 @@ def test_driver_pcg_output_lines(tmp_path, solver, precond):
 
 
 @pytest.mark.gpu
+def test_driver_pcg_prints_the_iteration_table_at_the_default_print_level(tmp_path):
+    """the reference driver's default is prnt_info = 2 (solvers.c: HYPRE_PCGSetPrintLevel), at which hypre_PCGSolve prints one
+    row per iteration: Iters, ||r||_2, conv.rate, ||r||_2/||b||_2.  Parity unpinned (no HYPRE here): the layout follows the
+    published pcg.c, the numbers are checked against the oracle's history."""
+    mtx = tmp_path / "poisson.mtx"
+    rp, ci, v = _write_poisson(mtx, 40, 30, shuffle_seed=2)
+    out = subprocess.run([os.path.join(HOST, "solver"), "-solver", "50", "-mtx", str(mtx), "-tol", "1e-8", "-maxit", "500"],
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert "Iters       ||r||_2     conv.rate  ||r||_2/||b||_2\n-----    ------------    ---------  ------------ \n" in out.stdout
+    rows = re.findall(r"^ *(\d+)    ([0-9.e+-]+)    ([0-9.]+)    ([0-9.e+-]+)$", out.stdout, re.M)
+    it = int(re.search(r"^Iterations = (\d+)$", out.stdout, re.M).group(1))
+    assert [int(r[0]) for r in rows] == list(range(1, it + 1))
+    n = rp.size - 1
+    o = oracle.pcg(rp, ci, v, np.ones(n), tol=1e-8, maxit=500, want_norms=True)
+    rel = np.array([float(r[3]) for r in rows])
+    k = min(it, o["iterations"])
+    assert np.allclose(rel[:k], o["rel_norms"][1:k + 1], rtol=1e-5)
+    absn = np.array([float(r[1]) for r in rows])
+    assert np.allclose(absn, rel * np.sqrt(n), rtol=1e-5)                      # ||b||_2 = sqrt(n) for b = 1
+    rate = np.array([float(r[2]) for r in rows])
+    assert np.allclose(rate[1:], absn[1:] / absn[:-1], atol=2e-6 + 1e-5 * rate[1:])
+
+
+@pytest.mark.gpu
 def test_driver_bicgstab_output_lines(tmp_path):
     # solver id 6 (solvers.c:517-564) on the same synthetic .mtx path
     mtx = tmp_path / "poisson.mtx"
