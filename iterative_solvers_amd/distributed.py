@@ -236,7 +236,7 @@ def bench_main(args, rank, local_rank, world, workloads, hbm_peak):
     dist.all_reduce(nnz_t)
     nnz = int(nnz_t.item())
     dinfo = A.diag_info()
-    kname = {1: "vector", 2: "stream", 3: "split", 4: "pattern", 5: "sweep"}.get(dinfo.kernel, str(dinfo.kernel))
+    kname = {1: "vector", 2: "stream", 3: "split", 4: "pattern", 5: "sweep", 6: "vsweep"}.get(dinfo.kernel, str(dinfo.kernel))
     if rank == 0:
         ms = dt * 1e3 / args.steps
         csr_bytes = 12 * nnz + (108 if precond else 92) * n
