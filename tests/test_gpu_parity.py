@@ -1136,6 +1136,8 @@ def test_full_size_config2_properties():
 def test_allocator_keeps_and_reuses_large_blocks():
     """freed device arrays of 1 MB and more wait in the library's free list and serve the next request of their size;
     mk_memory_trim() returns them to the driver (include/mk_krylov.h mk_memory_info / mk_memory_trim)"""
+    if os.environ.get("MK_NO_ALLOC_CACHE") or os.environ.get("MK_ALLOC_CACHE_MB"):
+        pytest.skip("the free list is switched off or resized by the environment")
     mk.init(0)
     mk.memory_trim()
     n = 3 * (1 << 20)                                   # 24 MB of doubles
