@@ -151,6 +151,7 @@ struct mk_matrix {
   mk::SweepEntry *etab = nullptr;  // device, 32 entries
   bool sweep_auto = false;         // enough parallelism for the sweep kernel to be the default
   bool sweep_streamed = false;     // the plan matches column offsets only: values are streamed from val[] (spmv_vsweep_kernel)
+  unsigned short *sweep_perm = nullptr;   // sweep kernel, rows of more than 8 entries: row pair each lane of a chunk owns (ncp x C/2)
   mutable int vsweep_lds_set = 0;
   mutable int sweep_bpc[6] = {0, 0, 0, 0, 0, 0};
   mutable int sweep_lds_set[6] = {0, 0, 0, 0, 0, 0};   // dynamic LDS above 48 KB needs a one-time opt-in per kernel

@@ -313,6 +313,31 @@ static int plan_sweep(mk_matrix *A, const std::vector<int> &tab, const std::vect
   MK_HIP(hipStreamSynchronize(ctx().stream));
   A->sweep = new SweepArgs(S);
   A->sweep_streamed = !with_values;
+  // Long rows (27-point: the kernel is bound by vector issue, and the selects are most of it): deal the row pairs of a chunk
+  // so that those with incomplete rows (grid boundaries) come first.  The pairs of one plane in the middle of the grid
+  // decide; whether a wave really owns complete rows only is tested per step in the kernel.
+  static const int no_perm = getenv("MK_SWEEP_NO_PERM") ? atoi(getenv("MK_SWEEP_NO_PERM")) : 0;
+  if (with_values && !contiguous && len > 8 && S.K >= 3 && !no_perm) {
+    const int T = S.C / 2;
+    const int64_t row0 = (int64_t)(S.K / 2) * S.P;
+    const int64_t nrow = std::min<int64_t>(S.P, A->nrows - row0);
+    std::vector<unsigned short> ids((size_t)std::max<int64_t>(nrow, 1));
+    MK_HIP(hipMemcpy(ids.data(), A->pat + row0, sizeof(unsigned short) * (size_t)nrow, hipMemcpyDeviceToHost));
+    const unsigned fullm = len >= 32 ? 0xffffffffu : (1u << len) - 1u;
+    std::vector<unsigned short> perm((size_t)S.ncp * T);
+    for (int cp = 0; cp < S.ncp; cp++) {
+      int w = 0;
+      for (int pass = 0; pass < 2; pass++)
+        for (int q = 0; q < T; q++) {
+          const int64_t r = (int64_t)cp * S.C + 2 * q;
+          bool partial = false;
+          if (r < nrow) partial = mask[ids[r]] != fullm || (r + 1 < nrow && mask[ids[r + 1]] != fullm);
+          if (partial == (pass == 0)) perm[(size_t)cp * T + w++] = (unsigned short)q;
+        }
+    }
+    MK_TRY(dev_alloc(&A->sweep_perm, perm.size()));
+    MK_HIP(hipMemcpy(A->sweep_perm, perm.data(), sizeof(unsigned short) * perm.size(), hipMemcpyHostToDevice));
+  }
   // one diagonal entry in the base pattern and every row keeps it: 1/diag is one number (fused Jacobi-PCG step)
   int ndiag = 0;
   for (int u = 0; u < len; u++) ndiag += (off_of(base, u) == 0);
@@ -1106,7 +1131,7 @@ __global__ __launch_bounds__(T, T == 512 ? 2 : 1) void spmv_sweep_kernel(
     const unsigned *__restrict__ pmask, int npat, const double *__restrict__ x, double *__restrict__ y, double alpha, double beta, double *__restrict__ slab,
     const int *__restrict__ done, const double *__restrict__ rhs, const double *__restrict__ extra,
     PcgState *st, const double *__restrict__ slab_in, int nblocks_in, int stride_in, double *__restrict__ xupd,
-    int flags, double *__restrict__ norms) {
+    int flags, double *__restrict__ norms, const unsigned short *__restrict__ perm) {
   // MODE 0: y = alpha A x + beta y.  1: y = A x, partials of <y,x>, <x,x>.  2: Jacobi sweep.
   // MODE 3 (fused CG, first kernel of a step): partials of <A x, x>, <x,x> only, nothing stored.
   // MODE 4 (second kernel; x is CG's p): alpha = gamma / <A x, x> from slab_in (K2's prologue), then
@@ -1180,7 +1205,11 @@ __global__ __launch_bounds__(T, T == 512 ? 2 : 1) void spmv_sweep_kernel(
     const int k0 = (int)((int64_t)seg * S.K / S.nseg), k1 = (int)((int64_t)(seg + 1) * S.K / S.nseg);
     const int r0 = cp * C;
     const int rows_here = min(C, S.P - r0);
-    const int lr = 2 * tid;
+    // lw: the lane's place in the window fill (always 2 tid).  lr: the pair of rows it owns.  With a permutation table
+    // (rows of more than 8 entries) the pairs that hold boundary rows of the grid are dealt to the first lanes of the
+    // chunk, so that all other waves own complete rows only and take the multiply-add loop without the selects.
+    const int lw = 2 * tid;
+    const int lr = perm ? 2 * (int)perm[cp * T + tid] : lw;
     const double dvb = S.diag >= 0 ? S.dv : 0.0;
 
     // All loads that run ahead are UNCONDITIONAL (addresses clamped into the arrays instead of predicated):
@@ -1191,7 +1220,7 @@ __global__ __launch_bounds__(T, T == 512 ? 2 : 1) void spmv_sweep_kernel(
     const int rlast = (nr - 1) & ~1;
     constexpr int NLR = (MODE == 5) ? NL : 1;   // second window stream (the residual) only in MODE 5
     auto load_slab = [&](int j, d2_t(&reg)[NL], d2_t(&regr)[NLR]) {   // window of plane j
-      const int g0 = min(j, k1) * S.P + r0 - S.wlo + lr;
+      const int g0 = min(j, k1) * S.P + r0 - S.wlo + lw;
 #pragma unroll
       for (int i = 0; i < NL; i++) {
         const int g = min(max(g0 + i * 2 * T, 0), xlast);
@@ -1208,7 +1237,7 @@ __global__ __launch_bounds__(T, T == 512 ? 2 : 1) void spmv_sweep_kernel(
       double *dst = ring + slot * sw + tid;
 #pragma unroll
       for (int i = 0; i < NL; i++) {
-        const int wi = lr + i * 2 * T;   // position in the window
+        const int wi = lw + i * 2 * T;   // position in the window
         if (wi < sw) {
           d2_t v = reg[i];
           if (MODE == 5) {
@@ -1282,9 +1311,43 @@ __global__ __launch_bounds__(T, T == 512 ? 2 : 1) void spmv_sweep_kernel(
         const bool two = g + 1 < nr;
         const unsigned mA = smask[id0 & 0xffffu];
         const unsigned mB = two ? smask[min(id0 >> 16, (unsigned)npat - 1u)] : 0u;
-        const char *wl = reinterpret_cast<const char *>(ring) + tid * 8;
+        const char *wl = reinterpret_cast<const char *>(ring) + (lr >> 1) * 8;
         double s0 = 0.0, s1 = 0.0;
-        for (int u0 = 0; u0 < S.len; u0 += 8) {
+        int u0 = 0;
+        if (perm != nullptr) {
+          // every row of the wave holds the whole base pattern: whole batches without the selects (same operations on
+          // the same operands in the same order)
+          const unsigned fullm = S.len >= 32 ? 0xffffffffu : (1u << S.len) - 1u;
+          if (__all(mA == fullm && mB == fullm)) {
+            for (; u0 + 8 <= S.len; u0 += 8) {
+              typedef int i16f_t __attribute__((ext_vector_type(16)));
+              const i16f_t *eb = reinterpret_cast<const i16f_t *>(etab + jb * 32 + u0);
+              const i16f_t b0 = eb[0], b1 = eb[1];
+              int off[8], off1[8];
+              double vv[8];
+#define MK_ENTF(U, B, Q)                                                                                  \
+  off[U] = B[4 * Q];                                                                                      \
+  off1[U] = B[4 * Q + 1];                                                                                 \
+  vv[U] = __longlong_as_double((long long)(((unsigned long long)(unsigned)B[4 * Q + 3] << 32) | (unsigned)B[4 * Q + 2]));
+              MK_ENTF(0, b0, 0) MK_ENTF(1, b0, 1) MK_ENTF(2, b0, 2) MK_ENTF(3, b0, 3)
+              MK_ENTF(4, b1, 0) MK_ENTF(5, b1, 1) MK_ENTF(6, b1, 2) MK_ENTF(7, b1, 3)
+#undef MK_ENTF
+              double p0[8], p1[8];
+#pragma unroll
+              for (int u = 0; u < 8; u++) {
+                p0[u] = *reinterpret_cast<const double *>(wl + off[u]);
+                p1[u] = *reinterpret_cast<const double *>(wl + off1[u]);
+              }
+              __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+              for (int u = 0; u < 8; u++) {
+                asm("v_fma_f64 %0, %1, %2, %3" : "=v"(s0) : "s"(vv[u]), "v"(p0[u]), "v"(s0));
+                asm("v_fma_f64 %0, %1, %2, %3" : "=v"(s1) : "s"(vv[u]), "v"(p1[u]), "v"(s1));
+              }
+            }
+          }
+        }
+        for (; u0 < S.len; u0 += 8) {
           // Eight entries per batch by two 64-byte scalar loads (scalar cache).  The table is stored once per
           // ring slot with the LDS offsets of that slot already worked out, which also makes the compiler
           // re-load it per step instead of keeping all 32 entries in SGPRs for the whole kernel (it did, and
@@ -1460,7 +1523,7 @@ static int launch_sweep(const mk_matrix *A, double alpha, const double *x, doubl
     }                                                                                                                      \
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(TT), lds, c.stream, S, A->etab, A->nrows, A->ncols, A->pat,     \
                        A->pmask, A->npat, x, y, alpha, beta, slab, done, rhs, extra, st, slab_in, nblocks_in, stride_in,  \
-                       xupd, flags, norms);                                                                                \
+                       xupd, flags, norms, A->sweep_perm);                                                                 \
   }
   if (T == 256 && nl == 2) MK_LAUNCH_SW(2, 256)
   else if (T == 256 && nl == 3) MK_LAUNCH_SW(3, 256)
