@@ -1347,7 +1347,7 @@ __global__ __launch_bounds__(T, T == 512 ? 2 : 1) void spmv_sweep_kernel(
             }
           }
         }
-        for (; u0 < S.len; u0 += 8) {
+        for (; u0 + 4 < S.len; u0 += 8) {   // (four entries or fewer left: the half batch below)
           // Eight entries per batch by two 64-byte scalar loads (scalar cache).  The table is stored once per
           // ring slot with the LDS offsets of that slot already worked out, which also makes the compiler
           // re-load it per step instead of keeping all 32 entries in SGPRs for the whole kernel (it did, and
@@ -1387,6 +1387,27 @@ __global__ __launch_bounds__(T, T == 512 ? 2 : 1) void spmv_sweep_kernel(
             const int ma = __builtin_amdgcn_sbfe(ka, u, 1), mb = __builtin_amdgcn_sbfe(kb, u, 1);
             s0 = bit_select(ma, t0, s0);
             s1 = bit_select(mb, t1, s1);
+          }
+        }
+        if (u0 < S.len) {   // the last one to four entries (27 = 3 x 8 + 3): half a batch, half the reads and selects
+          typedef int i16h_t __attribute__((ext_vector_type(16)));
+          const i16h_t b0 = *reinterpret_cast<const i16h_t *>(etab + jb * 32 + u0);
+          double p0[4], p1[4], vv[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            p0[u] = *reinterpret_cast<const double *>(wl + b0[4 * u]);
+            p1[u] = *reinterpret_cast<const double *>(wl + b0[4 * u + 1]);
+            vv[u] = __longlong_as_double((long long)(((unsigned long long)(unsigned)b0[4 * u + 3] << 32) | (unsigned)b0[4 * u + 2]));
+          }
+          const int ka = (int)(mA >> u0), kb = (int)(mB >> u0);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            double t0, t1;
+            asm("v_fma_f64 %0, %1, %2, %3" : "=v"(t0) : "s"(vv[u]), "v"(p0[u]), "v"(s0));
+            asm("v_fma_f64 %0, %1, %2, %3" : "=v"(t1) : "s"(vv[u]), "v"(p1[u]), "v"(s1));
+            s0 = bit_select(__builtin_amdgcn_sbfe(ka, u, 1), t0, s0);
+            s1 = bit_select(__builtin_amdgcn_sbfe(kb, u, 1), t1, s1);
           }
         }
         d2_t out;
