@@ -288,8 +288,13 @@ def test_spmv_pattern_and_sweep_ragged_sizes(n, hb):
         assert np.allclose(xj.get(), oj["x"], rtol=1e-12, atol=0)
 
 
-@pytest.mark.parametrize("seed,P,K,nbase", [(1, 640, 9, 9), (2, 1024, 5, 14), (3, 96, 40, 6), (4, 2048, 12, 12)])
-def test_spmv_sweep_kernel_random_patterns(seed, P, K, nbase):
+@pytest.mark.parametrize("seed,P,K,nbase,full_frac", [(1, 640, 9, 9, 0.6), (2, 1024, 5, 14, 0.6), (3, 96, 40, 6, 0.6), (4, 2048, 12, 12, 0.6),
+                                                       # long patterns, nearly all rows complete: the lanes of a chunk are dealt
+                                                       # boundary pairs first, complete waves run select-free batches, the last
+                                                       # 1-4 entries take the half batch (27 = 3 x 8 + 3, 17 = 2 x 8 + 1, 20, 32)
+                                                       (5, 512, 12, 27, 0.995), (6, 768, 9, 20, 0.99), (7, 256, 30, 32, 0.98),
+                                                       (8, 640, 8, 17, 0.999), (9, 1024, 6, 27, 1.0)])
+def test_spmv_sweep_kernel_random_patterns(seed, P, K, nbase, full_frac):
     """not a grid: a random base pattern with offsets a*P + b (a in {-1,0,1}, unsymmetric, unsorted), every row a
     random sub-list of it chosen among ~20 masks, row-dependent sub-lists at the matrix ends.  Pattern and sweep
     kernels must reproduce the serial reference bit for bit (same pairs, same order)."""
@@ -310,7 +315,7 @@ def test_spmv_sweep_kernel_random_patterns(seed, P, K, nbase):
     for m in masks:
         m[offs == 0] = True
     which = rng.integers(0, len(masks), n)
-    which[rng.random(n) < 0.6] = 0                        # most rows carry the full pattern
+    which[rng.random(n) < full_frac] = 0                  # most rows carry the full pattern
     rows_c, rows_v = [], []
     for i in range(n):
         keep = masks[which[i]] & (i + offs >= 0) & (i + offs < n)
