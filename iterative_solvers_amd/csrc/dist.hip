@@ -106,6 +106,7 @@ struct mk_dist_matrix {
   mk_matrix offd;              // n_offd_rows x n_ghost (compressed rows)
   int *offd_rows = nullptr;    // local row of each offd row
   int n_offd_rows = 0;
+  int gap0 = 0, gap1 = 0;      // the longest run of local rows [gap0, gap1) that touch no ghost (a z-slab: all but its end planes)
   int offd_lanes = 1;
   int *ghost_global = nullptr; // device, sorted global ids of the ghosts
   std::vector<int> h_ghost;
@@ -359,8 +360,19 @@ static int split_block(mk_matrix *A, mk_dist_matrix *D) {
                              D->offd.col, D->offd.val);
   D->h_ghost.resize((size_t)D->n_ghost);
   if (D->n_ghost) MK_HIP(hipMemcpyAsync(D->h_ghost.data(), D->ghost_global, sizeof(int) * D->n_ghost, hipMemcpyDeviceToHost, c.stream));
+  std::vector<int> h_rows((size_t)D->n_offd_rows);
+  if (D->n_offd_rows) MK_HIP(hipMemcpyAsync(h_rows.data(), D->offd_rows, sizeof(int) * D->n_offd_rows, hipMemcpyDeviceToHost, c.stream));
   MK_HIP(hipStreamSynchronize(c.stream));
   MK_HIP(hipGetLastError());
+  {   // longest run of rows between two consecutive rows that touch ghosts (the list is ascending)
+    int prev = -1;
+    D->gap0 = 0; D->gap1 = 0;
+    for (int i = 0; i <= D->n_offd_rows; i++) {
+      const int next = (i < D->n_offd_rows) ? h_rows[i] : (int)nl;
+      if (next - (prev + 1) > D->gap1 - D->gap0) { D->gap0 = prev + 1; D->gap1 = next; }
+      prev = next;
+    }
+  }
   dev_free(flags); dev_free(cnt_d); dev_free(cnt_o); dev_free(has_o); dev_free(d_tot);
   // receive plan: ghosts are sorted by global id, owners are contiguous row blocks (host logic shared with the CPU tests)
   D->recv_cnt.assign(D->nranks, 0);
@@ -1036,6 +1048,7 @@ int mk_dist_jacobi_solve(int R, mk_jacobi **solvers, mk_dist_matrix **A, mk_vect
   MK_REQUIRE_INIT();
   MK_TRY(check_ranks("mk_dist_jacobi_solve", R, A));
   if (!solvers || !b || !x) return fail(MK_ERR_INVALID, "mk_dist_jacobi_solve: null argument");
+  static const int no_gap = getenv("MK_NO_EXTRA_GAP") ? atoi(getenv("MK_NO_EXTRA_GAP")) : 0;   // A/B: the sweep reads the whole off-rank vector
   Context &c = ctx();
   mk_jacobi *S0 = solvers[0];
   for (int r = 0; r < R; r++) {
@@ -1101,7 +1114,8 @@ int mk_dist_jacobi_solve(int R, mk_jacobi **solvers, mk_dist_matrix **A, mk_vect
       MK_D((launch_offd<false, true>(D, cur[r], W[r].extra, 1.0, nullptr, &W[r].state->done, nullptr)));
       const mk_matrix &M = D->diag;
       int sweep_blocks = 0;
-      const int src = launch_jacobi_sweep(&D->diag, b[r]->d, W[r].extra, cur[r], nxt[r], W[r].slab, &W[r].state->done, &sweep_blocks);
+      const int src = launch_jacobi_sweep(&D->diag, b[r]->d, W[r].extra, cur[r], nxt[r], W[r].slab, &W[r].state->done, &sweep_blocks,
+                                          no_gap ? 0 : D->gap0, no_gap ? 0 : D->gap1);
       if (src == MK_OK) {
         blocks[r] = sweep_blocks;
       } else if (src == MK_ERR_UNSUPPORTED) {

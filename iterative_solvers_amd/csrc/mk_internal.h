@@ -194,7 +194,7 @@ int launch_spmv_dot(const mk_matrix *A, const double *x, double *y, double *slab
 // xnew = xold + D^-1 (rhs - A xold - extra) with the partial of the squared residual in slab component 0;
 // MK_ERR_UNSUPPORTED (no error text) when A is not served by the stream kernel
 int launch_jacobi_sweep(const mk_matrix *A, const double *rhs, const double *extra, const double *xold, double *xnew,
-                        double *slab, const int *done, int *nblocks);
+                        double *slab, const int *done, int *nblocks, int extra_gap0 = 0, int extra_gap1 = 0);
 
 // fused CG on matrices served by the sweep kernel: two more modes of it, the scalar logic of the step (alpha,
 // breakdown tests, iteration counter) runs in the second one's prologue.

@@ -1270,6 +1270,15 @@ __global__ __launch_bounds__(T, T == 512 ? 2 : 1) void spmv_sweep_kernel(
     };
     const double *aux = (MODE == 2 || MODE == 4) ? rhs : (MODE == 0 && beta != 0.0) ? y : nullptr;
     constexpr bool kExtra = (MODE == 2 || MODE == 4);
+    // MODE 2, row-block Jacobi: `extra` (the off-rank product) is zero on every row that touches no ghost.  The caller names
+    // the largest run of such rows [gap0, gap1) (in nblocks_in / stride_in, which this mode has no other use for): lanes
+    // inside it all read the pair at gap0 -- the load stays unconditional, HBM sees one line instead of 8 B per row.
+    const int gap0 = (MODE == 2) ? nblocks_in : 0, gap1 = (MODE == 2) ? stride_in : 0;
+    auto load_extra = [&](int j) -> d2_t {
+      int g = min(row_of(j), rlast);
+      if (MODE == 2) g = (g >= gap0 && g + 1 < gap1) ? gap0 : g;
+      return MK_SWEEP_LD(reinterpret_cast<const d2_t *>(reinterpret_cast<const char *>(extra) + ((unsigned)g << 3)));
+    };
 
     // Three register stages, each used in place: stage (k mod 3) holds slab k+2 at step k, is written to the
     // ring and at once re-loaded with slab k+5 -- no register-to-register rotation (a move of a register
@@ -1287,17 +1296,17 @@ __global__ __launch_bounds__(T, T == 512 ? 2 : 1) void spmv_sweep_kernel(
     d2_t xu0 = ax0, xu1 = ax0, xu2 = ax0;
     unsigned id0 = load_ids(k0);
     if (aux) ax0 = load_pair(aux, k0);
-    if (kExtra && extra) ex0 = load_pair(extra, k0);
+    if (kExtra && extra) ex0 = load_extra(k0);
     if (MODE == 4) xu0 = load_pair(xupd, k0);
     load_slab(k0 + 2, st0, rt0);
     unsigned id1 = load_ids(k0 + 1);
     if (aux) ax1 = load_pair(aux, k0 + 1);
-    if (kExtra && extra) ex1 = load_pair(extra, k0 + 1);
+    if (kExtra && extra) ex1 = load_extra(k0 + 1);
     if (MODE == 4) xu1 = load_pair(xupd, k0 + 1);
     load_slab(k0 + 3, st1, rt1);
     unsigned id2 = load_ids(k0 + 2);
     if (aux) ax2 = load_pair(aux, k0 + 2);
-    if (kExtra && extra) ex2 = load_pair(extra, k0 + 2);
+    if (kExtra && extra) ex2 = load_extra(k0 + 2);
     if (MODE == 4) xu2 = load_pair(xupd, k0 + 2);
     load_slab(k0 + 4, st2, rt2);
     __syncthreads();
@@ -1466,7 +1475,7 @@ __global__ __launch_bounds__(T, T == 512 ? 2 : 1) void spmv_sweep_kernel(
       // look-ahead loads into the registers just consumed: ids / aux of plane k+3, slab k+5
       idr = load_ids(k + 3);
       if (aux) axr = load_pair(aux, k + 3);
-      if (kExtra && extra) exr = load_pair(extra, k + 3);
+      if (kExtra && extra) exr = load_extra(k + 3);
       if (MODE == 4) xur = load_pair(xupd, k + 3);
       load_slab(k + 5, st, rt);
       __syncthreads();
@@ -1775,10 +1784,11 @@ int launch_spmv(const mk_matrix *A, double alpha, const double *x, double beta, 
 // one Jacobi sweep through the stream kernel; returns MK_ERR_UNSUPPORTED when the matrix does not
 // use that kernel (the caller then runs its own lane-per-row sweep)
 int launch_jacobi_sweep(const mk_matrix *A, const double *rhs, const double *extra, const double *xold, double *xnew,
-                        double *slab, const int *done, int *nblocks) {
+                        double *slab, const int *done, int *nblocks, int extra_gap0, int extra_gap1) {
   MK_TRY(analyse_matrix(const_cast<mk_matrix *>(A)));
   if (A->kernel == MK_SPMV_VSWEEP) return launch_vsweep(A, 2, 1.0, xold, 0.0, xnew, slab, done, nblocks, rhs, extra);
-  if (A->kernel == MK_SPMV_SWEEP) return launch_sweep<2>(A, 1.0, xold, 0.0, xnew, slab, done, nblocks, rhs, extra);
+  if (A->kernel == MK_SPMV_SWEEP)   // rows [extra_gap0, extra_gap1) have extra == 0: the kernel reads one pair for all of them
+    return launch_sweep<2>(A, 1.0, xold, 0.0, xnew, slab, done, nblocks, rhs, extra, nullptr, nullptr, (extra_gap0 + 1) & ~1, extra_gap1);
   if (A->kernel == MK_SPMV_PATTERN) return launch_pattern<2>(A, 1.0, xold, 0.0, xnew, slab, done, nblocks, rhs, extra);
   if (A->kernel != MK_SPMV_STREAM) return MK_ERR_UNSUPPORTED;
   return launch_stream<2>(A, 1.0, xold, 0.0, xnew, slab, done, nblocks, rhs, extra);
