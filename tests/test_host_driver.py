@@ -454,3 +454,21 @@ def test_driver_rejects_stale_cache(tmp_path):
     assert "Loaded binary CSR cache" in third.stderr
     pick = lambda o: re.findall(r"^(Iterations = \d+|Final Relative Residual Norm = \S+)$", o.stdout, re.M)
     assert pick(second) == pick(third) != pick(first)
+
+
+@pytest.mark.gpu
+def test_bench_cpu_configs_mode_runs_config_1():
+    """bench.py --cpu-configs c1: the oracle's CPU solve and the GPU solve of BASELINE configs[0] side by side (SURVEY 8d);
+    both must take the same number of iterations to the same residual"""
+    import json
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--cpu-configs", "c1"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads(out.stdout.strip().splitlines()[-1])
+    assert rec["rows"] == 1024 * 1024 and rec["omp_threads"] >= 1 and rec["cpu_model"]
+    for tol in ("tol1e-06", "tol1e-10"):
+        t = rec[tol]
+        assert abs(t["cpu_iterations"] - t["gpu_iterations"]) <= 2
+        assert t["gpu_it_per_s"] > t["cpu_it_per_s"] > 0
+        assert t["gpu_rel_res"] < float(tol[3:]) and t["cpu_rel_res"] < float(tol[3:])
