@@ -95,6 +95,10 @@ struct mk_comm {
   ncclComm_t coll = nullptr, p2p = nullptr;
   hipStream_t comm_stream = nullptr;
   hipEvent_t ev_ready = nullptr, ev_halo = nullptr;
+  // matrices created on this communicator; mk_comm_destroy() on a communicator that still has users only marks it, the
+  // last matrix to go tears it down (a host language's finaliser order is not ours to choose)
+  int users = 0;
+  bool dead = false;
 };
 
 struct mk_dist_matrix {
@@ -528,15 +532,16 @@ static int all_reduce(int R, mk_dist_matrix **A, double **bufs, int count) {
 // max_blocks: room left in the slab the partials go to (they sit behind the diag kernel's partials)
 template <bool DOT, bool SET = false>
 static int launch_offd(const mk_dist_matrix *D, const double *xext, double *y, double alpha, double *slab, const int *done, int *nblocks,
-                       int max_blocks = 1024) {
+                       int max_blocks = 1024, hipStream_t stream = nullptr) {
   Context &c = ctx();
+  if (stream == nullptr) stream = c.stream;
   const int G = D->offd_lanes;
   const int rows_per_block = 256 / G;
   if (max_blocks < 1) return fail(MK_ERR_UNSUPPORTED, "row-block CG: the diag block's %d reduction partials leave no room for the off-rank product's", kSlabStride - max_blocks);
   int blocks = std::max(1, std::min((D->n_offd_rows + rows_per_block - 1) / rows_per_block, std::min(1024, max_blocks)));
   if (nblocks) *nblocks = blocks;
   if (D->n_offd_rows == 0 && !DOT) return MK_OK;
-#define MK_OFFD(GG) case GG: hipLaunchKernelGGL((offd_spmv_kernel<GG, DOT, SET>), dim3(blocks), dim3(256), 0, c.stream, D->n_offd_rows, \
+#define MK_OFFD(GG) case GG: hipLaunchKernelGGL((offd_spmv_kernel<GG, DOT, SET>), dim3(blocks), dim3(256), 0, stream, D->n_offd_rows, \
     D->offd.rowptr, D->offd.col, D->offd.val, D->offd_rows, xext + D->n_local, xext, y, alpha, slab, done, HaloFuse()); break;
   switch (G) { MK_OFFD(1) MK_OFFD(2) MK_OFFD(4) MK_OFFD(8) MK_OFFD(16) MK_OFFD(32) MK_OFFD(64) default: return fail(MK_ERR_INVALID, "offd lanes"); }
 #undef MK_OFFD
@@ -703,9 +708,7 @@ int mk_comm_all_reduce_host(mk_comm *cm, double *values, int count, int op) {
   return MK_OK;
 }
 
-int mk_comm_destroy(mk_comm *cm) {
-  if (!cm) return MK_OK;
-  if (ctx().ready) (void)hipDeviceSynchronize();
+static void comm_release(mk_comm *cm) {
   if (cm->local) {
     LocalWorld *W = cm->world;
     W->comms[cm->rank] = nullptr;
@@ -726,6 +729,16 @@ int mk_comm_destroy(mk_comm *cm) {
     if (cm->comm_stream) (void)hipStreamDestroy(cm->comm_stream);
   }
   delete cm;
+}
+
+int mk_comm_destroy(mk_comm *cm) {
+  if (!cm) return MK_OK;
+  if (ctx().ready) (void)hipDeviceSynchronize();
+  if (cm->users > 0) {   // matrices still refer to it
+    cm->dead = true;
+    return MK_OK;
+  }
+  comm_release(cm);
   return MK_OK;
 }
 
@@ -741,6 +754,7 @@ int mk_dist_matrix_create(mk_matrix *A, int64_t n_global, const int64_t *row_sta
                 (long long)A->ncols, (long long)(row_start[me + 1] - row_start[me]), (long long)n_global);
   mk_dist_matrix *D = new mk_dist_matrix();
   D->comm = comm; D->nranks = P; D->rank = me;
+  if (comm) comm->users++;
   D->n_global = n_global;
   D->row_start.assign(row_start, row_start + P + 1);
   D->row_begin = row_start[me]; D->row_end = row_start[me + 1];
@@ -761,7 +775,13 @@ int mk_dist_matrix_create(mk_matrix *A, int64_t n_global, const int64_t *row_sta
       rc = build_plan_rccl(D);
     }
   }
-  if (rc != MK_OK) { release_dist(D); delete D; return rc; }
+  if (rc != MK_OK) {
+    if (comm && comm->local && comm->world && comm->world->mats[me] == D) comm->world->mats[me] = nullptr;
+    if (comm) comm->users--;
+    release_dist(D);
+    delete D;
+    return rc;
+  }
   mk_matrix_destroy(A);   // the block with global column ids is consumed
   *out = D;
   return MK_OK;
@@ -770,9 +790,11 @@ int mk_dist_matrix_create(mk_matrix *A, int64_t n_global, const int64_t *row_sta
 int mk_dist_matrix_destroy(mk_dist_matrix *D) {
   if (!D) return MK_OK;
   if (ctx().ready) (void)hipDeviceSynchronize();
-  if (D->comm && D->comm->local && D->comm->world) D->comm->world->mats[D->rank] = nullptr;
+  mk_comm *cm = D->comm;
+  if (cm && cm->local && cm->world) cm->world->mats[D->rank] = nullptr;
   release_dist(D);
   delete D;
+  if (cm && --cm->users == 0 && cm->dead) comm_release(cm);
   return MK_OK;
 }
 
@@ -1061,7 +1083,11 @@ int mk_dist_jacobi_solve(int R, mk_jacobi **solvers, mk_dist_matrix **A, mk_vect
   struct JW { double *xalt = nullptr, *extra = nullptr, *slab = nullptr, *buf = nullptr; JacobiState *state = nullptr; };
   std::vector<JW> W(R);
   std::vector<double *> cur(R), nxt(R), bufs(R);
-  std::vector<int> blocks(R), vb(R);
+  std::vector<int> blocks(R), vb(R), split(R, 0), pb(R, 0), pe(R, 0), nplanes(R, 0);
+  // split sweep (see the loop): default over RCCL, where the exchange has a latency worth hiding; in a local world (one GPU,
+  // nothing to hide, two more launches per rank) only on request.  MK_JACOBI_SPLIT=0 / 1 forces it off / on.
+  static const int env_split = getenv("MK_JACOBI_SPLIT") ? atoi(getenv("MK_JACOBI_SPLIT")) : -1;
+  const bool want_split = env_split >= 0 ? env_split != 0 : (A[0]->comm != nullptr && !A[0]->comm->local);
   auto cleanup = [&]() {
     (void)hipDeviceSynchronize();
     for (auto &w : W) { dev_free(w.xalt); dev_free(w.extra); dev_free(w.slab); dev_free(w.buf); dev_free(w.state); }
@@ -1084,6 +1110,14 @@ int mk_dist_jacobi_solve(int R, mk_jacobi **solvers, mk_dist_matrix **A, mk_vect
     const int G = D->diag.lanes;
     blocks[r] = (int)std::max<int64_t>(1, std::min<int64_t>((D->n_local + 256 / G - 1) / (256 / G), std::min<int64_t>((int64_t)c.num_cus * 8, kSlabStride)));
     solvers[r]->iterations = 0; solvers[r]->rel_res_norm = 0.0; solvers[r]->converged = 0;
+    int P = 0, K = 0;
+    if (want_split && !no_gap && A[0]->comm != nullptr && sweep_planes(&D->diag, &P, &K) && D->n_offd_rows > 0) {
+      nplanes[r] = K;
+      pb[r] = (int)((D->gap0 + P - 1) / P);     // first plane wholly inside the ghost-free run of rows
+      pe[r] = (int)(D->gap1 / P);               // one past the last such plane
+      if (D->gap1 >= (int)D->n_local) pe[r] = K;
+      split[r] = pe[r] - pb[r] >= 8 && (pb[r] > 0 || pe[r] < K);
+    }
   }
   JacobiState *hst = static_cast<JacobiState *>(c.pinned);
   // ||b||^2
@@ -1108,6 +1142,35 @@ int mk_dist_jacobi_solve(int R, mk_jacobi **solvers, mk_dist_matrix **A, mk_vect
   long long k = 0;
   int checks = 0;
   for (;;) {
+    // Split sweep (diag block on the sweep kernel, enough planes inside the ghost-free run of rows): the planes whose rows
+    // touch no ghost are swept while the halo of x travels and the off-rank product forms on the halo's stream; the few
+    // boundary planes follow once both are in.  Same kernel, same rows, same arithmetic as the one-launch sweep.
+    bool all_split = true;
+    for (int r = 0; r < R; r++) all_split = all_split && split[r];
+    if (all_split) {
+      MK_D(halo_exchange(R, A, cur.data(), true));
+      for (int r = 0; r < R; r++)
+        MK_D((launch_offd<false, true>(A[r], cur[r], W[r].extra, 1.0, nullptr, &W[r].state->done, nullptr, 1024, halo_stream(A[r]))));
+      MK_D(halo_mark(A[0]));
+      for (int r = 0; r < R; r++) {   // interior planes
+        int nb = 0;
+        MK_D(launch_jacobi_sweep(&A[r]->diag, b[r]->d, W[r].extra, cur[r], nxt[r], W[r].slab, &W[r].state->done, &nb, A[r]->gap0, A[r]->gap1,
+                                 pb[r], pe[r]));
+        blocks[r] = nb;
+      }
+      for (int r = 0; r < R; r++) {   // boundary planes once ghosts and off-rank product are in
+        MK_D(halo_wait(A[r], true));
+        const int ranges[2][2] = {{0, pb[r]}, {pe[r], nplanes[r]}};
+        for (int q = 0; q < 2; q++) {
+          if (ranges[q][1] <= ranges[q][0]) continue;
+          int nb = 0;
+          if (blocks[r] >= kSlabStride - 8) { cleanup(); return fail(MK_ERR_UNSUPPORTED, "row-block Jacobi: too many reduction partials for a split sweep"); }
+          MK_D(launch_jacobi_sweep(&A[r]->diag, b[r]->d, W[r].extra, cur[r], nxt[r], W[r].slab + blocks[r], &W[r].state->done, &nb, A[r]->gap0,
+                                   A[r]->gap1, ranges[q][0], ranges[q][1]));
+          blocks[r] += nb;
+        }
+      }
+    } else {
     MK_D(halo_exchange(R, A, cur.data(), false));
     for (int r = 0; r < R; r++) {
       mk_dist_matrix *D = A[r];
@@ -1127,6 +1190,7 @@ int mk_dist_jacobi_solve(int R, mk_jacobi **solvers, mk_dist_matrix **A, mk_vect
         cleanup();
         return src;
       }
+    }
     }
     const bool last = (k >= S0->max_iter);
     if (k % S0->check_every == 0 || last) {

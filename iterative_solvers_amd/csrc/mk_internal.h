@@ -82,7 +82,8 @@ struct SweepArgs {
   int ncp;        // chunks of C rows per plane
   int nseg;       // segments the K planes are cut into (grid = ncp * nseg blocks, set per launch)
   int wlo, sw;    // window: rows [r0 - wlo, r0 - wlo + sw) of a plane per slab (both even)
-  int K;          // planes = ceil(nrows / P)
+  int K;          // planes = ceil(nrows / P) (per launch: planes of the launch's range)
+  int kb;         // first plane of the launch (0 unless a caller sweeps a sub-range of the planes)
   int diag;       // index of the last entry with offset 0, or -1
   double dv;      // its value
 };
@@ -194,7 +195,10 @@ int launch_spmv_dot(const mk_matrix *A, const double *x, double *y, double *slab
 // xnew = xold + D^-1 (rhs - A xold - extra) with the partial of the squared residual in slab component 0;
 // MK_ERR_UNSUPPORTED (no error text) when A is not served by the stream kernel
 int launch_jacobi_sweep(const mk_matrix *A, const double *rhs, const double *extra, const double *xold, double *xnew,
-                        double *slab, const int *done, int *nblocks, int extra_gap0 = 0, int extra_gap1 = 0);
+                        double *slab, const int *done, int *nblocks, int extra_gap0 = 0, int extra_gap1 = 0,
+                        int plane_begin = 0, int plane_end = 0);
+// planes of the sweep plan (rows per plane, number of planes); 0 when the matrix is not served by the sweep kernel
+int sweep_planes(const mk_matrix *A, int *rows_per_plane, int *nplanes);
 
 // fused CG on matrices served by the sweep kernel: two more modes of it, the scalar logic of the step (alpha,
 // breakdown tests, iteration counter) runs in the second one's prologue.

@@ -288,6 +288,7 @@ static int plan_sweep(mk_matrix *A, const std::vector<int> &tab, const std::vect
     S.P = S.C * std::max(G, 1);
   }
   S.K = (int)((A->nrows + S.P - 1) / S.P);
+  S.kb = 0;
   S.ncp = (S.P + S.C - 1) / S.C;
   S.nseg = 1;
   MK_TRY(dev_alloc(&A->pmask, (size_t)npat));
@@ -1202,7 +1203,7 @@ __global__ __launch_bounds__(T, T == 512 ? 2 : 1) void spmv_sweep_kernel(
     // all row / column indices fit 29 bits here (plan_sweep): 32-bit arithmetic throughout, one v_med3 per clamp
     const int nr = (int)nrows;
     const int cp = lid % S.ncp, seg = lid / S.ncp;
-    const int k0 = (int)((int64_t)seg * S.K / S.nseg), k1 = (int)((int64_t)(seg + 1) * S.K / S.nseg);
+    const int k0 = S.kb + (int)((int64_t)seg * S.K / S.nseg), k1 = S.kb + (int)((int64_t)(seg + 1) * S.K / S.nseg);
     const int r0 = cp * C;
     const int rows_here = min(C, S.P - r0);
     // lw: the lane's place in the window fill (always 2 tid).  lr: the pair of rows it owns.  With a permutation table
@@ -1502,10 +1503,15 @@ template <int MODE>
 static int launch_sweep(const mk_matrix *A, double alpha, const double *x, double beta, double *y, double *slab,
                         const int *done, int *nblocks, const double *rhs = nullptr, const double *extra = nullptr,
                         PcgState *st = nullptr, const double *slab_in = nullptr, int nblocks_in = 0, int stride_in = kSlabStride,
-                        double *xupd = nullptr, int flags = 0, double *norms = nullptr) {
+                        double *xupd = nullptr, int flags = 0, double *norms = nullptr, int plane_begin = 0, int plane_end = 0) {
   Context &c = ctx();
   if (!A->sweep || A->sweep_streamed) return fail(MK_ERR_UNSUPPORTED, "spmv: the sweep kernel needs rows that are sub-lists of one (offsets, values) pattern with offsets a*P + b");
   SweepArgs S = *A->sweep;
+  if (plane_end > plane_begin) {   // a caller's sub-range of the planes (row-block Jacobi: interior / boundary launches)
+    if (plane_begin < 0 || plane_end > S.K) return fail(MK_ERR_INVALID, "spmv: planes [%d, %d) of %d", plane_begin, plane_end, S.K);
+    S.kb = plane_begin;
+    S.K = plane_end - plane_begin;
+  }
   const size_t lds = (size_t)kSweepNS * S.sw * 8 + (size_t)A->npat * 4;
   static const int env_bpc = getenv("MK_SWEEP_BPC") ? atoi(getenv("MK_SWEEP_BPC")) : 0;
   int per_cu = env_bpc > 0 ? env_bpc : A->sweep_bpc[MODE];
@@ -1784,14 +1790,23 @@ int launch_spmv(const mk_matrix *A, double alpha, const double *x, double beta, 
 // one Jacobi sweep through the stream kernel; returns MK_ERR_UNSUPPORTED when the matrix does not
 // use that kernel (the caller then runs its own lane-per-row sweep)
 int launch_jacobi_sweep(const mk_matrix *A, const double *rhs, const double *extra, const double *xold, double *xnew,
-                        double *slab, const int *done, int *nblocks, int extra_gap0, int extra_gap1) {
+                        double *slab, const int *done, int *nblocks, int extra_gap0, int extra_gap1, int plane_begin, int plane_end) {
   MK_TRY(analyse_matrix(const_cast<mk_matrix *>(A)));
   if (A->kernel == MK_SPMV_VSWEEP) return launch_vsweep(A, 2, 1.0, xold, 0.0, xnew, slab, done, nblocks, rhs, extra);
   if (A->kernel == MK_SPMV_SWEEP)   // rows [extra_gap0, extra_gap1) have extra == 0: the kernel reads one pair for all of them
-    return launch_sweep<2>(A, 1.0, xold, 0.0, xnew, slab, done, nblocks, rhs, extra, nullptr, nullptr, (extra_gap0 + 1) & ~1, extra_gap1);
+    return launch_sweep<2>(A, 1.0, xold, 0.0, xnew, slab, done, nblocks, rhs, extra, nullptr, nullptr, (extra_gap0 + 1) & ~1, extra_gap1,
+                           nullptr, 0, nullptr, plane_begin, plane_end);
+  if (plane_end > plane_begin) return fail(MK_ERR_UNSUPPORTED, "jacobi sweep: plane ranges need the sweep kernel");
   if (A->kernel == MK_SPMV_PATTERN) return launch_pattern<2>(A, 1.0, xold, 0.0, xnew, slab, done, nblocks, rhs, extra);
   if (A->kernel != MK_SPMV_STREAM) return MK_ERR_UNSUPPORTED;
   return launch_stream<2>(A, 1.0, xold, 0.0, xnew, slab, done, nblocks, rhs, extra);
+}
+
+int sweep_planes(const mk_matrix *A, int *rows_per_plane, int *nplanes) {
+  if (A->kernel != MK_SPMV_SWEEP || !A->sweep || A->sweep_streamed) return 0;
+  if (rows_per_plane) *rows_per_plane = A->sweep->P;
+  if (nplanes) *nplanes = A->sweep->K;
+  return 1;
 }
 
 int launch_sweep_cg_dots(const mk_matrix *A, const double *p, double *slab_out, PcgState *st, int *nblocks) {

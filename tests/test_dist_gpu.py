@@ -1,6 +1,8 @@
 """Distributed path on ONE GPU: several logical ranks in one process ("local world"): same
 partition / ghost map / diag-offd split / solver code as over RCCL, with the exchange done by
 device copies.  Checked against the global oracle results."""
+import os
+
 import numpy as np
 import pytest
 
@@ -253,6 +255,81 @@ def test_dist_jacobi_banded_matches_oracle(world):
     assert np.allclose(np.concatenate([x.get() for x in xs]), o["x"], rtol=1e-12, atol=0)
     if world > 1:
         assert As[0].info()["n_ghost"] == 3 and As[1].info()["n_offd_rows"] in (3, 6)
+
+
+_SPLIT_SNIPPET = r"""
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+import oracle
+import iterative_solvers_amd as mk
+from iterative_solvers_amd import distributed as mkd
+mk.init(0)
+def blocks(rp, ci, v, n, rs, comms):
+    out = []
+    for r in range(len(rs) - 1):
+        lo, hi = int(rs[r]), int(rs[r + 1])
+        blk = mk.Matrix.from_csr(hi - lo, n, (rp[lo:hi + 1] - rp[lo]).astype(np.int32), ci[rp[lo]:rp[hi]], v[rp[lo]:rp[hi]])
+        out.append(mkd.DistMatrix(blk, n, rs, comms[r]))
+    return out
+cases = [("banded", 60000, np.array([0, 20000, 41000, 60000], np.int64), 10),      # uneven blocks
+         ("banded", 40001, np.array([0, 10000, 20000, 30000, 40001], np.int64), 1),
+         ("lap7", (12, 10, 60), None, 5)]
+for kind, shape, rs, every in cases:
+    if kind == "banded":
+        n = shape
+        rp, ci, v = oracle.banded_csr(n, 3)
+    else:
+        rp, ci, v = oracle.stencil_csr(7, *shape)
+        n = rp.size - 1
+        v = v.copy(); v[ci == np.repeat(np.arange(n), np.diff(rp))] += 1.0      # strictly dominant
+        rs = mkd.slab_row_start(*shape, 3)
+    o = oracle.jacobi(rp, ci, v, np.ones(n), tol=1e-9, maxit=300, check_every=every)
+    comms = mkd.Comm.local_world(len(rs) - 1)
+    As = blocks(rp, ci, v, n, rs, comms)
+    for a in As:
+        a.set_spmv_kernel(mk.SPMV_SWEEP)          # small blocks would default to the pattern kernel
+    assert all(a.diag_info().kernel == mk.SPMV_SWEEP for a in As), [a.diag_info().kernel for a in As]
+    bs = [a.vector(fill=1.0) for a in As]
+    xs = [a.vector(fill=0.0) for a in As]
+    Ss = [mk.Jacobi(max_iter=300, tol=1e-9, check_every=every) for _ in As]
+    res = mkd.dist_jacobi_solve(Ss, As, bs, xs)
+    assert res[0]["converged"] == o["converged"] and res[0]["iterations"] == o["iterations"], (kind, res[0], o["iterations"])
+    assert np.isclose(res[0]["rel_res_norm"], o["rel_res_norm"], rtol=1e-9)
+    assert np.allclose(np.concatenate([x.get() for x in xs]), o["x"], rtol=1e-12, atol=0), kind
+    del As, bs, xs, comms
+print("split ok")
+"""
+
+
+@pytest.mark.parametrize("split", ["1", "0"])
+def test_dist_jacobi_split_sweep_matches_oracle(split):
+    """row-block Jacobi with the sweep cut into an interior launch (beside the halo and the off-rank product) and boundary
+    launches: the default over RCCL, forced here in a local world through MK_JACOBI_SPLIT (read once per process, hence the
+    child process); '0' runs the same cases through the one-launch order"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MK_JACOBI_SPLIT=split)
+    out = subprocess.run([sys.executable, "-c", _SPLIT_SNIPPET, root], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0 and "split ok" in out.stdout, out.stderr[-3000:]
+
+
+def test_comm_may_be_destroyed_before_its_matrices():
+    """a host language's finalisers run in any order: destroying the communicators first must leave the matrices usable
+    for their own destruction (the last matrix tears the communicator down)"""
+    rp, ci, v = oracle.stencil_csr(5, 12, 12)
+    n = rp.size - 1
+    rs = mkd.even_row_start(n, 2)
+    comms = mkd.Comm.local_world(2)
+    As = _blocks(rp, ci, v, n, rs, comms)
+    L = mk.load()
+    for c in comms:                       # communicators first (the wrappers must not destroy them a second time)
+        L.mk_comm_destroy(c.h)
+        c.h = None
+    del comms
+    infos = [A.info() for A in As]        # still readable
+    assert infos[0]["n_ghost"] > 0
+    del As                                # the last matrix releases the world
 
 
 def test_dist_errors():
