@@ -58,6 +58,56 @@ static void rmat() {
   CK(mk_vector_destroy(x)); CK(mk_vector_destroy(y)); CK(mk_matrix_destroy(A));
 }
 
+// variable coefficients (vsweep), 27-point rows (boundary-pairs-first table, half batch), banded (planes of chunks), static entry
+static void more_kernels() {
+  struct Case { int kind, nx, ny, nz; unsigned long long seed; int kernel; } cases[] = {
+      {7, 96, 80, 40, 3, 6}, {27, 48, 40, 36, 0, 5}, {5, 300, 200, 1, 0, 5}, {7, 64, 64, 64, 9, 6}};
+  for (const Case &c : cases) {
+    const int64_t n = (int64_t)c.nx * c.ny * c.nz;
+    mk_matrix *A = nullptr;
+    if (c.seed) CK(mk_matrix_generate_stencil_scaled(c.kind, c.nx, c.ny, c.nz, c.seed, 0, n, &A));
+    else CK(mk_matrix_generate_stencil(c.kind, c.nx, c.ny, c.nz, 0, n, &A));
+    const bool forced = mk_matrix_set_spmv_kernel(A, c.kernel, 0) == 0;
+    mk_vector *x, *y; CK(mk_vector_create(n, &x)); CK(mk_vector_create(n, &y)); CK(mk_vector_fill(x, 1.0));
+    CK(mk_spmv(A, 2.0, x, 0.0, y)); CK(mk_spmv(A, 1.0, x, -1.0, y));
+    double a, b2; CK(mk_spmv_dot(A, x, y, &a, &b2)); CK(mk_spmv_dot_static(A, x, y, &a, &b2));
+    mk_pcg *S; CK(mk_pcg_create(&S)); CK(mk_pcg_set_max_iter(S, 25)); CK(mk_pcg_set_tol(S, 0.0)); CK(mk_pcg_set_precond(S, 1));
+    CK(mk_vector_fill(y, 0.0)); CK(mk_pcg_setup(S, A, x, y)); CK(mk_pcg_solve(S, A, x, y)); CK(mk_pcg_destroy(S));
+    mk_jacobi *J; CK(mk_jacobi_create(&J)); CK(mk_jacobi_set_max_iter(J, 12)); CK(mk_vector_fill(y, 0.0));
+    CK(mk_jacobi_setup(J, A, x, y)); CK(mk_jacobi_solve(J, A, x, y)); CK(mk_jacobi_destroy(J));
+    printf("  kind %d %dx%dx%d seed %llu kernel %d%s\n", c.kind, c.nx, c.ny, c.nz, c.seed, c.kernel, forced ? "" : " (not eligible, default kernel)");
+    CK(mk_vector_destroy(x)); CK(mk_vector_destroy(y)); CK(mk_matrix_destroy(A));
+  }
+  mk_matrix *B = nullptr;
+  CK(mk_matrix_generate_banded(300003, 3, 0, 300003, &B));
+  mk_vector *x, *y; CK(mk_vector_create(300003, &x)); CK(mk_vector_create(300003, &y)); CK(mk_vector_fill(x, 1.0));
+  CK(mk_spmv(B, 1.0, x, 0.0, y));
+  mk_jacobi *J; CK(mk_jacobi_create(&J)); CK(mk_jacobi_set_max_iter(J, 12)); CK(mk_vector_fill(y, 0.0));
+  CK(mk_jacobi_setup(J, B, x, y)); CK(mk_jacobi_solve(J, B, x, y)); CK(mk_jacobi_destroy(J));
+  CK(mk_vector_destroy(x)); CK(mk_vector_destroy(y)); CK(mk_matrix_destroy(B));
+  long long in_use = 0, idle = 0;
+  CK(mk_memory_info(&in_use, &idle)); CK(mk_memory_trim()); CK(mk_memory_info(&in_use, &idle));
+  if (idle != 0) { fprintf(stderr, "memory trim left %lld idle bytes\n", idle); exit(1); }
+}
+
+// communicators destroyed before the matrices created on them (a host language's finaliser order)
+static void comm_first() {
+  const int R = 3, nx = 16, ny = 12, nz = 18;
+  const int64_t n = (int64_t)nx * ny * nz;
+  std::vector<int64_t> rs(R + 1);
+  for (int r = 0; r <= R; r++) rs[r] = (int64_t)nx * ny * ((int64_t)nz * r / R);
+  std::vector<mk_comm *> comms(R);
+  CK(mk_comm_create_local(R, comms.data()));
+  std::vector<mk_dist_matrix *> D(R);
+  for (int r = 0; r < R; r++) {
+    mk_matrix *blk = nullptr;
+    CK(mk_matrix_generate_stencil(7, nx, ny, nz, rs[r], rs[r + 1], &blk));
+    CK(mk_dist_matrix_create(blk, n, rs.data(), comms[r], &D[r]));
+  }
+  for (int r = 0; r < R; r++) CK(mk_comm_destroy(comms[r]));
+  for (int r = R - 1; r >= 0; r--) CK(mk_dist_matrix_destroy(D[r]));
+}
+
 static void world(int nx, int ny, int nz, int R, bool rccl, int precond) {
   const int64_t n = (int64_t)nx * ny * nz;
   std::vector<int64_t> rs(R + 1);
@@ -97,6 +147,7 @@ static void world(int nx, int ny, int nz, int R, bool rccl, int precond) {
 }
 
 int main() {
+  setvbuf(stdout, nullptr, _IONBF, 0);
   CK(mk_init(0));
   printf("single matrix\n");
   one_matrix(64, 64, 64);
@@ -104,7 +155,10 @@ int main() {
   one_matrix(128, 128, 96);
   printf("rmat\n");
   rmat();
+  printf("more kernels\n");
+  more_kernels();
   printf("row blocks\n");
+  comm_first();
   world(64, 64, 64, 4, false, 0);
   world(128, 128, 128, 8, false, 0);
   world(128, 128, 128, 8, false, 1);

@@ -7,7 +7,7 @@ cd "$(dirname "$0")/.."
 mkdir -p tools/build_asan
 SRC=iterative_solvers_amd/csrc
 FLAGS="-O1 -g -std=c++17 --offload-arch=gfx950 -Wno-unused-function -ffp-contract=on -Xarch_host -fsanitize=address -Xarch_host -fno-omit-frame-pointer"
-for f in context spmv convert krylov bicgstab gmres generate dist; do
+for f in context spmv vsweep convert krylov bicgstab gmres generate dist; do
   if [ ! tools/build_asan/$f.o -nt $SRC/$f.hip ]; then /opt/rocm/bin/hipcc $FLAGS -c $SRC/$f.hip -o tools/build_asan/$f.o & fi
 done
 wait
