@@ -17,6 +17,9 @@ At N = 1 the line also carries
   * `secondary`: BASELINE.json configs[1] (256^3 Jacobi-PCG) and configs[2] (R-MAT scale 24: COO->CSR + SpMV);
   * `cpu_baseline`: the oracle's OpenMP CG on the full 512^3 operator on the host cores.
 
+`python bench.py --cpu-configs c1,c2,c3` is a separate mode (one JSON line per configuration, not the contract line): the
+oracle's CPU solve / product / conversion of BASELINE configs[0..2] beside the GPU's, SURVEY.md 8(d)'s per-config baselines.
+
 For N > 1 the driver starts one rank per GPU through torch.distributed.run; started plainly (`python bench.py --gpus N`,
 no WORLD_SIZE in the environment) this script starts the N ranks itself.  torch is used for the rendezvous/barrier
 only, the solve runs inside libmi355_krylov.so.
