@@ -1165,3 +1165,37 @@ def test_allocator_keeps_and_reuses_large_blocks():
     assert mk.memory_info()[1] >= 8 * n
     mk.memory_trim()
     assert mk.memory_info() == (live0, 0)
+
+
+_RELABEL_SNIPPET = r"""
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+import oracle
+import iterative_solvers_amd as mk
+mk.init(0)
+for scale, ne in ((16, 1 << 20), (18, 1 << 21)):
+    r, c, v = oracle.rmat_coo(scale, ne, seed=scale)
+    n = 1 << scale
+    rp, ci, vv = oracle.coo_to_csr(n, r, c, v)
+    A = mk.Matrix.from_device_coo(mk.DeviceCOO.from_host(n, n, r, c, v))
+    A.set_spmv_kernel(mk.SPMV_SPLIT)
+    xh = np.random.default_rng(scale).normal(size=n)
+    x, y = mk.Vector(n, values=xh), mk.Vector(n)
+    A.spmv(x, y)               # first product: builds the column relabelling, with MK_RELABEL_CHECK=1 it verifies its degrees
+    ref = oracle.csr_spmv(rp, ci, vv, xh)
+    scale_y = oracle.csr_spmv(rp, ci, np.abs(vv), np.abs(xh))
+    assert np.all(np.abs(y.get() - ref) <= 1e-12 * np.maximum(scale_y, 1e-300))
+print("relabel ok")
+"""
+
+
+def test_column_degrees_per_xcd_match_device_scope_count():
+    """the column relabelling counts column degrees with workgroup-scope atomics into one copy per XCD (picked by the
+    hardware's XCC id); MK_RELABEL_CHECK=1 makes the library recount with device-scope atomics and fail on any difference.
+    Child process: MK_RELABEL_MIN_COLS is read once per process."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MK_RELABEL_CHECK="1", MK_RELABEL_MIN_COLS="1000")
+    out = subprocess.run([sys.executable, "-c", _RELABEL_SNIPPET, root], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0 and "relabel ok" in out.stdout, (out.stdout[-500:], out.stderr[-3000:])
