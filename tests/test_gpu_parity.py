@@ -41,7 +41,10 @@ def test_coo_to_csr_golden(name):
 
 @pytest.mark.parametrize("nrows,nnz,skew", [(1, 100, 0), (3, 50000, 0), (255, 10000, 0), (257, 100000, 0),
                                             (65536, 300000, 1), (65537, 300000, 0), (1 << 20, 2000000, 1),
-                                            ((1 << 24) + 5, 3000000, 0)])
+                                            ((1 << 24) + 5, 3000000, 0),
+                                            # entry counts at and around whole sort tiles (4096) and whole rounds of 8 tiles
+                                            (300, 4096, 0), (300, 4097, 0), (300, 4095, 0), (70000, 65536, 0), (70000, 8 * 4096 + 1, 1),
+                                            (70000, 9 * 4096, 0), (1 << 17, 24 * 4096 - 1, 1)])
 def test_coo_to_csr_random_vs_oracle(nrows, nnz, skew):
     rng = np.random.default_rng(nrows + nnz)
     if skew:
@@ -56,6 +59,19 @@ def test_coo_to_csr_random_vs_oracle(nrows, nnz, skew):
     sr, sc, sv = mk.sort_coo_row(nrows, nrows, rows, cols, vals)
     osr, osc, osv = oracle.sort_coo_row(nrows, rows, cols, vals)
     assert np.array_equal(sr, osr) and np.array_equal(sc, osc) and _same_bits(sv, osv)
+
+
+def test_coo_to_csr_degenerate_orders():
+    """already sorted input (no sort pass runs), reverse order, every entry in one row, in the last row: bit-exact"""
+    rng = np.random.default_rng(7)
+    nrows, nnz = 5000, 20000
+    cols = rng.integers(0, nrows, nnz).astype(np.int32)
+    vals = rng.normal(size=nnz)
+    for rows in (np.sort(rng.integers(0, nrows, nnz)).astype(np.int32), np.sort(rng.integers(0, nrows, nnz))[::-1].astype(np.int32).copy(),
+                 np.full(nnz, 17, np.int32), np.full(nnz, nrows - 1, np.int32)):
+        rp, ci, v = mk.coo_to_csr(nrows, nrows, rows, cols, vals)
+        orp, oci, ov = oracle.coo_to_csr(nrows, rows, cols, vals)
+        assert np.array_equal(rp, orp) and np.array_equal(ci, oci) and _same_bits(v, ov)
 
 
 def test_coo_rejects_bad_indices():
