@@ -62,7 +62,11 @@ __global__ void diag_inverse_kernel(int64_t nrows, const int *__restrict__ rowpt
 // --------------------------------------------------------- column-index compression
 // Lossless: the product reads exactly the same (column, value) pairs in the same order.
 constexpr int kPatSlots = 1 << 16;
-constexpr int kPatMaxLen = 32;      // rows longer than this are not worth a table entry
+constexpr int kPatMaxLen = 128;     // longer rows are not looked at (3 dof per node on a 27-point grid: 81 entries, 81 patterns)
+static int pat_max_len() {
+  static const int v = getenv("MK_PAT_MAX_LEN") ? atoi(getenv("MK_PAT_MAX_LEN")) : kPatMaxLen;
+  return v;
+}
 constexpr int kPatMaxProbes = 512;
 constexpr int kPatMaxInts = 8192;   // table must fit 32 KB of LDS beside the value stage
 
@@ -355,7 +359,7 @@ template <bool VAL>
 static int try_compress(mk_matrix *A) {
   static const int no_idx = getenv("MK_NO_INDEX_COMPRESSION") ? atoi(getenv("MK_NO_INDEX_COMPRESSION")) : 0;
   static const int no_val = getenv("MK_NO_VALUE_COMPRESSION") ? atoi(getenv("MK_NO_VALUE_COMPRESSION")) : 0;
-  if (no_idx || (VAL && no_val) || A->pat || A->nrows == 0 || A->info.max_row_len > kPatMaxLen || A->info.max_row_len < 1) return MK_OK;
+  if (no_idx || (VAL && no_val) || A->pat || A->nrows == 0 || A->info.max_row_len > pat_max_len() || A->info.max_row_len < 1) return MK_OK;
   Context &c = ctx();
   const int pml = A->info.max_row_len;
   unsigned long long *keys = nullptr;
@@ -458,7 +462,10 @@ int analyse_matrix(mk_matrix *A) {
   // stream kernel: 256/G rows per chunk, G lanes per row in the row pass; usable when the
   // longest row times the rows per chunk fits the LDS budget (regular matrices)
   int sl = 1;
-  while (sl < 64 && (double)sl * 8.0 < I.mean_row_len) sl *= 2;
+  static const double env_div = getenv("MK_STREAM_DIV") ? atof(getenv("MK_STREAM_DIV")) : 16.0;
+  while (sl < 64 && (double)sl * env_div < I.mean_row_len) sl *= 2;
+  static const int env_sl = getenv("MK_STREAM_LANES") ? atoi(getenv("MK_STREAM_LANES")) : 0;   // tuning: 1..64, power of two
+  if (env_sl >= 1 && env_sl <= 64 && !(env_sl & (env_sl - 1))) sl = env_sl;
   while (sl < 64 && (int64_t)(kThreads / sl) * I.max_row_len > kStreamMaxCap) sl *= 2;
   A->stream_lanes = sl;
   A->stream_cap = (int)((std::max<int64_t>(64, (int64_t)(kThreads / sl) * I.max_row_len) + 3) & ~(int64_t)3);
@@ -724,10 +731,23 @@ __global__ __launch_bounds__(kThreads) void spmv_stream_kernel(
         sum += vj[t] * xj[t];
         if (MODE == 2 && cj[t] == (int)row) { dj = b + g + t * G; dv = vj[t]; }   // the last stored diagonal entry wins
       }
-    for (int j = b + g + 8 * G; j < e; j += G) {   // rows longer than 8 lanes' worth
-      const int cc = sc[j] + cadd;
-      sum += sv[j] * x[cc];
-      if (MODE == 2 && cc == (int)row) { dj = j; dv = sv[j]; }
+    for (int j0 = b + g + 8 * G; j0 < e; j0 += 4 * G) {   // rows longer than 8 lanes' worth: batches of 4, gathers issued together
+      int c4[4];
+      double v4[4], x4[4];
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        const int j = min(j0 + t * G, lastj);
+        c4[t] = sc[j] + cadd;
+        v4[t] = sv[j];
+      }
+#pragma unroll
+      for (int t = 0; t < 4; t++) x4[t] = x[c4[t]];
+#pragma unroll
+      for (int t = 0; t < 4; t++)
+        if (j0 + t * G < e) {
+          sum += v4[t] * x4[t];
+          if (MODE == 2 && c4[t] == (int)row) { dj = j0 + t * G; dv = v4[t]; }
+        }
     }
     if (G > 1) {
       sum = group_sum<G>(sum);

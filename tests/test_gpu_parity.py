@@ -642,6 +642,72 @@ def test_spmv_stream_ragged_rows():
         A.set_spmv_kernel(lanes_kernel)
         _check_spmv(A, rp, ci, v, n, n, rng, alpha=1.5, beta=0.25)
 
+def _hex3_csr(nx, ny, nz):
+    """3 unknowns per node of an nx x ny x nz grid, 27 node neighbours x 3x3 blocks: up to 81 entries per row"""
+    nn = nx * ny * nz
+    idx = np.arange(nn)
+    ix, iy, iz = idx % nx, (idx // nx) % ny, idx // (nx * ny)
+    rr, cc = [], []
+    for dz in (-1, 0, 1):
+        for dy in (-1, 0, 1):
+            for dx in (-1, 0, 1):
+                ok = (ix + dx >= 0) & (ix + dx < nx) & (iy + dy >= 0) & (iy + dy < ny) & (iz + dz >= 0) & (iz + dz < nz)
+                rr.append(idx[ok])
+                cc.append(idx[ok] + dx + dy * nx + dz * nx * ny)
+    nrow, ncol = np.concatenate(rr), np.concatenate(cc)
+    rows = (nrow[:, None, None] * 3 + np.arange(3)[None, :, None] + np.zeros((1, 1, 3), np.int64)).reshape(-1)
+    cols = (ncol[:, None, None] * 3 + np.arange(3)[None, None, :] + np.zeros((1, 3, 1), np.int64)).reshape(-1)
+    order = np.lexsort((cols, rows))
+    rows, cols = rows[order], cols[order]
+    rp = np.concatenate([[0], np.cumsum(np.bincount(rows, minlength=3 * nn))]).astype(np.int32)
+    return 3 * nn, rp, cols.astype(np.int32), rows
+
+
+def test_spmv_stream_long_rows():
+    """rows of 24..95 entries (several lanes per row, more than 8 entries per lane: the batched tail of the
+    row pass), with and without an index-pattern table, and one Jacobi solve through the same kernel"""
+    rng = np.random.default_rng(21)
+    # a) block-structured: 81 entries per interior row, patterns shared -> column indices from the table
+    n, rp, ci, rows = _hex3_csr(11, 9, 7)
+    v = rng.normal(size=ci.size)
+    A = mk.Matrix.from_csr(n, n, rp, ci, v)
+    i = A.info()
+    assert i.kernel == mk.SPMV_STREAM and i.max_row_len == 81 and 81 <= i.index_patterns <= 2048
+    _check_spmv(A, rp, ci, v, n, n, rng)
+    _check_spmv(A, rp, ci, v, n, n, rng, alpha=-0.3, beta=2.0)
+    # b) irregular: 60..95 random columns per row, no two rows alike -> col[] is read
+    n2 = 5003
+    lens = rng.integers(60, 96, n2)
+    lens[::17] = 95
+    rp2 = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    rows2 = np.repeat(np.arange(n2), lens)
+    ci2 = rng.integers(0, n2, rp2[-1])
+    ci2 = ci2[np.lexsort((ci2, rows2))].astype(np.int32)
+    v2 = rng.normal(size=rp2[-1])
+    B = mk.Matrix.from_csr(n2, n2, rp2, ci2, v2)
+    assert B.info().kernel == mk.SPMV_STREAM and B.info().index_patterns == 0
+    _check_spmv(B, rp2, ci2, v2, n2, n2, rng, alpha=1.25, beta=-0.5)
+    yx, xx = None, None
+    xh = rng.normal(size=n2)
+    x, y = mk.Vector(n2, values=xh), mk.Vector(n2)
+    yx, xx = B.spmv_dot(x, y)
+    ref = oracle.csr_spmv(rp2, ci2, v2, xh)
+    assert np.isclose(yx, ref @ xh, rtol=1e-11, atol=1e-9) and np.isclose(xx, xh @ xh, rtol=1e-12)
+    # c) Jacobi on a): the sweep picks the diagonal out of the row as it goes by, also from the tail batch
+    vd = v.copy()
+    absum = np.bincount(rows, weights=np.abs(v), minlength=n)
+    diag = (ci == rows)
+    vd[diag] = 1.5 * absum[rows[diag]]
+    o = oracle.jacobi(rp, ci, vd, np.ones(n), tol=1e-10, maxit=300, check_every=1)
+    D = mk.Matrix.from_csr(n, n, rp, ci, vd)
+    b, xs = mk.Vector(n, fill=1.0), mk.Vector(n, fill=0.0)
+    S = mk.Jacobi(max_iter=300, tol=1e-10, check_every=1)
+    S.setup(D, b, xs)
+    res = S.solve(D, b, xs)
+    assert res["converged"] == 1 == o["converged"] and res["iterations"] == o["iterations"]
+    assert np.allclose(xs.get(), o["x"], rtol=1e-11, atol=0)
+
+
 
 @pytest.mark.parametrize("name", GOLDEN_CASES)
 def test_spmv_on_golden_matrices(name):

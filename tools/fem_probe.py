@@ -1,0 +1,98 @@
+#!/usr/bin/env python3
+"""SpMV on synthetic FEM-like matrices (the shape of the authors' SuiteSparse inputs, scripts/bench_all_gpu:2 of the
+reference: Bump_2911, Serena, ldoor -- 40-80 entries per row, every entry its own value), built on the host with numpy
+and uploaded as CSR.  Two generators:
+  hex3 <nodes_per_side>            3 dof per node on a hexahedral mesh: 27 node neighbours x 3x3 blocks, up to 81 per row
+  nine <side>                      2-D 9-point stencil
+  rand <rows> <mean_len> <halfwin> row lengths uniform in mean*[2/3,4/3], columns in blocks of 3 anywhere in +-halfwin
+Prints the time of every eligible kernel and the fraction of the CSR byte model (12 nnz + 20 n + 4) over 8 TB/s.
+usage: fem_probe.py [hex3 64 | rand 2000000 45 3000] ...   (several cases may follow each other)"""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import iterative_solvers_amd as mk
+
+
+def hex3(N):
+    nn = N ** 3
+    idx = np.arange(nn)
+    ix, iy, iz = idx % N, (idx // N) % N, idx // (N * N)
+    rr, cc = [], []
+    for dz in (-1, 0, 1):
+        for dy in (-1, 0, 1):
+            for dx in (-1, 0, 1):
+                ok = (ix + dx >= 0) & (ix + dx < N) & (iy + dy >= 0) & (iy + dy < N) & (iz + dz >= 0) & (iz + dz < N)
+                rr.append(idx[ok])
+                cc.append(idx[ok] + dx + dy * N + dz * N * N)
+    nrow, ncol = np.concatenate(rr), np.concatenate(cc)
+    rows = (nrow[:, None, None] * 3 + np.arange(3)[None, :, None] + np.zeros((1, 1, 3), np.int64)).reshape(-1)
+    cols = (ncol[:, None, None] * 3 + np.arange(3)[None, None, :] + np.zeros((1, 3, 1), np.int64)).reshape(-1)
+    order = np.lexsort((cols, rows))
+    rows, cols = rows[order], cols[order].astype(np.int32)
+    n = 3 * nn
+    rp = np.concatenate([[0], np.cumsum(np.bincount(rows, minlength=n))]).astype(np.int32)
+    return n, rp, cols
+
+
+def rand(n, mean, hw):
+    rng = np.random.default_rng(1)
+    lens = rng.integers(mean * 2 // 3, mean * 4 // 3 + 1, n)
+    rp = np.concatenate([[0], np.cumsum(lens)])
+    nnz = int(rp[-1])
+    rows = np.repeat(np.arange(n), lens)
+    base = rows + rng.integers(-hw, hw + 1, nnz)
+    ci = np.clip(base - base % 3 + (np.arange(nnz) % 3), 0, n - 1).astype(np.int32)
+    ci = ci[np.lexsort((ci, rows))]
+    return n, rp.astype(np.int32), ci
+
+
+def run(name, n, rp, ci):
+    nnz = ci.size
+    v = np.random.default_rng(0).normal(size=nnz)
+    A = mk.Matrix.from_csr(n, n, rp, ci, v)
+    mk.synchronize(); t0 = time.perf_counter()
+    i = A.info()          # first use: row statistics, kernel choice, index-pattern search
+    mk.synchronize(); t_an = (time.perf_counter() - t0) * 1e3
+    x, y = mk.Vector(n, fill=1.0), mk.Vector(n)
+    b = 12 * nnz + 20 * n + 4
+    out = [f"{name}: rows {n} mean {nnz / n:.1f} max {i.max_row_len} default {i.kernel} patterns {i.index_patterns} analysis {t_an:.2f} ms |"]
+    for k in (0, 1, 2, 3):
+        try:
+            A.set_spmv_kernel(k)
+        except mk.MkError:
+            continue
+        for _ in range(3):
+            A.spmv(x, y)
+        mk.timer_start()
+        for _ in range(20):
+            A.spmv(x, y)
+        ms = mk.timer_stop() / 20
+        out.append(f"k{k} {ms * 1e3:.0f} us {b / ms / 1e6 / 8000:.3f}")
+    print(" ".join(out), flush=True)
+
+
+def nine(N):
+    """2-D 9-point stencil on an N x N grid, every entry its own value"""
+    idx = np.arange(N * N)
+    ix, iy = idx % N, idx // N
+    rr, cc = [], []
+    for dy in (-1, 0, 1):
+        for dx in (-1, 0, 1):
+            ok = (ix + dx >= 0) & (ix + dx < N) & (iy + dy >= 0) & (iy + dy < N)
+            rr.append(idx[ok]); cc.append(idx[ok] + dx + dy * N)
+    rows, cols = np.concatenate(rr), np.concatenate(cc)
+    order = np.lexsort((cols, rows))
+    rows, cols = rows[order], cols[order].astype(np.int32)
+    rp = np.concatenate([[0], np.cumsum(np.bincount(rows, minlength=N * N))]).astype(np.int32)
+    return N * N, rp, cols
+
+
+args = sys.argv[1:] or ["hex3", "64"]
+mk.init(0)
+while args:
+    if args[0] == "nine":
+        run(f"nine {args[1]}", *nine(int(args[1]))); args = args[2:]
+    elif args[0] == "hex3":
+        run(f"hex3 {args[1]}", *hex3(int(args[1]))); args = args[2:]
+    else:
+        run(f"rand {args[1]} {args[2]} {args[3]}", *rand(int(args[1]), int(args[2]), int(args[3]))); args = args[4:]

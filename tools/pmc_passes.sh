@@ -9,7 +9,7 @@ for grp in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SMEM S
            "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum" \
            "SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM SQ_INSTS_SALU SQ_WAVES_EQ_64 SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INSTS_VMEM_WR"; do
   i=$((i+1))
-  timeout -s KILL 90 rocprofv3 --pmc $grp --output-format csv -d "$out/p$i" -- python3 tools/spmv_probe.py "$@" > "$out.p$i.log" 2>&1 || { echo "pass $i failed"; tail -5 "$out.p$i.log"; exit 1; }
+  timeout -s KILL 150 rocprofv3 --pmc $grp --output-format csv -d "$out/p$i" -- python3 ${PROBE:-tools/spmv_probe.py} "$@" > "$out.p$i.log" 2>&1 || { echo "pass $i failed"; tail -5 "$out.p$i.log"; exit 1; }
 done
 python3 - "$out" <<'PY'
 import csv, glob, sys, collections
