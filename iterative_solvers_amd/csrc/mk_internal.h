@@ -142,6 +142,8 @@ struct mk_matrix {
   // of 4 B per entry.  pat == nullptr -> not compressed.
   unsigned short *pat = nullptr;   // pattern id per row
   int *ptab = nullptr;             // npat x (pml+1) ints: length, offsets
+  int *stab = nullptr;             // stream kernel's two-level copy when patterns share shapes: [shapes: length, offsets - first offset][npat x (shape start, first offset)]
+  int stab_shape_ints = 0, stab_ints = 0;
   double *vtab = nullptr;          // npat x pml doubles when the rows of a pattern also share their values
                                    // (pattern kernel: neither col[] nor val[] nor rowptr[] is read)
   int *otab8 = nullptr;            // pattern kernel's padded copies of ptab / vtab (row stride p8 + 8 ints, p8 doubles)

@@ -12,6 +12,7 @@
 //   stream kernel : nnz-balanced chunks staged through LDS, rows split inside the chunk;
 //                   rows longer than a chunk are split over blocks (skewed / power-law rows).
 #include <cfloat>
+#include <map>
 
 #include "mk_internal.h"
 
@@ -354,6 +355,40 @@ static int plan_sweep(mk_matrix *A, const std::vector<int> &tab, const std::vect
   return MK_OK;
 }
 
+// Patterns that differ only by a shift (the unknowns of one mesh node: same neighbours, offsets one less per unknown)
+// share one "shape" = offsets minus the first offset.  The stream kernel keeps the whole table in LDS, so for long rows
+// the table decides how many blocks fit a CU: shapes + (shape, shift) per pattern instead of npat full rows.
+static int build_shape_table(mk_matrix *A, const std::vector<int> &tab) {
+  static const int off = getenv("MK_NO_SHAPE_TABLE") ? atoi(getenv("MK_NO_SHAPE_TABLE")) : 0;
+  const int npat = A->npat, pml = A->pml, stride = pml + 1;
+  if (off || npat < 2) return MK_OK;
+  std::map<std::vector<int>, int> start_of;   // shape (length, offsets - first) -> first int of its copy
+  std::vector<int> shapes, map2((size_t)npat * 2);
+  for (int q = 0; q < npat; q++) {
+    const int len = tab[(size_t)q * stride];
+    const int first = len > 0 ? tab[(size_t)q * stride + 1] : 0;
+    std::vector<int> key(1 + len);
+    key[0] = len;
+    for (int k = 0; k < len; k++) key[1 + k] = tab[(size_t)q * stride + 1 + k] - first;
+    auto it = start_of.find(key);
+    if (it == start_of.end()) {
+      it = start_of.emplace(key, (int)shapes.size()).first;
+      shapes.insert(shapes.end(), key.begin(), key.end());
+    }
+    map2[(size_t)q * 2] = it->second;
+    map2[(size_t)q * 2 + 1] = first;
+  }
+  if (shapes.size() & 1) shapes.push_back(0);
+  if ((shapes.size() + map2.size()) * 4 > (size_t)npat * stride * 3) return MK_OK;   // pays from a quarter saved
+  A->stab_shape_ints = (int)shapes.size();
+  shapes.insert(shapes.end(), map2.begin(), map2.end());
+  A->stab_ints = (int)shapes.size();
+  MK_TRY(dev_alloc(&A->stab, shapes.size()));
+  MK_HIP(hipMemcpyAsync(A->stab, shapes.data(), sizeof(int) * shapes.size(), hipMemcpyHostToDevice, ctx().stream));
+  MK_HIP(hipStreamSynchronize(ctx().stream));
+  return MK_OK;
+}
+
 // with_values: key = (offsets, values); the pattern kernel then needs neither col[] nor val[] nor rowptr[]
 template <bool VAL>
 static int try_compress(mk_matrix *A) {
@@ -404,6 +439,7 @@ static int try_compress(mk_matrix *A) {
       for (int q = 0; q < npat; q++)
         for (int k = 0; k < tab[(size_t)q * (pml + 1)]; k++) mo = std::max(mo, std::abs(tab[(size_t)q * (pml + 1) + 1 + k]));
       A->max_off = mo;
+      MK_TRY(build_shape_table(A, tab));
       if (VAL) {   // padded copies for the pattern kernel (layout: see spmv_pattern_kernel)
         const int P8 = (pml + 7) & ~7, SP = P8 + 8;
         std::vector<double> vals((size_t)npat * pml), v8((size_t)npat * P8, 0.0);
@@ -603,7 +639,7 @@ __global__ __launch_bounds__(kThreads) void spmv_stream_kernel(
     int64_t nrows, const int *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ val,
     const double *__restrict__ x, double *__restrict__ y, double alpha, double beta, double *__restrict__ slab,
     const int *__restrict__ done, int cap, const unsigned short *__restrict__ pat, const int *__restrict__ ptab,
-    int tab_ints, int pml, const double *__restrict__ rhs, const double *__restrict__ extra, int tile_p, int tile_t) {
+    int tab_ints, int shape_ints, int pml, const double *__restrict__ rhs, const double *__restrict__ extra, int tile_p, int tile_t) {
   // MODE 2 = one Jacobi sweep: y = x + D^-1 (rhs - A x - extra), D picked up from the row while it
   // streams by; slab component 0 receives the partial of ||rhs - A x - extra||^2
   if (done != nullptr && *done != 0) return;
@@ -692,8 +728,13 @@ __global__ __launch_bounds__(kThreads) void spmv_stream_kernel(
     if (COMP && have_row) pid = NT ? __builtin_nontemporal_load(pat + row) : pat[row];
     __syncthreads();
     const double *sv = sval + (cb - vb);
-    const int *sc = COMP ? scol + pid * (pml + 1) + 1 - b : scol + (cb - ib);   // sc[j]: column (or column - row) of entry j
-    const int cadd = COMP ? (int)row : 0;
+    int pbase = pid * (pml + 1), pshift = 0;
+    if (COMP && shape_ints > 0) {   // two-level table: shapes, then (shape start, first offset) per pattern
+      pbase = scol[shape_ints + 2 * pid];
+      pshift = scol[shape_ints + 2 * pid + 1];
+    }
+    const int *sc = COMP ? scol + pbase + 1 - b : scol + (cb - ib);   // sc[j]: column (or column - row - shift) of entry j
+    const int cadd = COMP ? (int)row + pshift : 0;
     // first 8 entries of the row (per lane): all gathers issued before anything waits
     const int lastj = max(e - 1, 0);
     int cj[8];
@@ -794,7 +835,10 @@ static int launch_stream_u(const mk_matrix *A, double alpha, const double *x, do
                            const int *done, int *nblocks, const double *rhs = nullptr, const double *extra = nullptr) {
   Context &c = ctx();
   const int G = A->stream_lanes, cap = A->stream_cap;
-  const int tab_ints = COMP ? A->npat * (A->pml + 1) : 0;
+  const bool shapes = COMP && A->stab != nullptr;
+  const int tab_ints = COMP ? (shapes ? A->stab_ints : A->npat * (A->pml + 1)) : 0;
+  const int *table = shapes ? A->stab : A->ptab;
+  const int shape_ints = shapes ? A->stab_shape_ints : 0;
   const size_t lds = (size_t)(cap + 2) * 8 + (COMP ? (size_t)tab_ints * 4 + 16 : (size_t)(cap + 8) * 4);  // cap is a multiple of 4
   const int64_t nchunks = (A->nrows + (kThreads / G) - 1) / (kThreads / G);
   // resident blocks per CU for this instantiation (registers + LDS), so the grid is one full wave of blocks
@@ -828,7 +872,7 @@ static int launch_stream_u(const mk_matrix *A, double alpha, const double *x, do
   case GG:                                                                                                         \
     hipLaunchKernelGGL((spmv_stream_kernel<GG, MODE, U, COMP, NT>), dim3((unsigned)blocks), dim3(kThreads), lds,      \
                        c.stream, A->nrows, A->rowptr, A->col, A->val, x, y, alpha, beta, slab, done, cap, A->pat,  \
-                       A->ptab, tab_ints, A->pml, rhs, extra, tile_p, tile_t);                                     \
+                       table, tab_ints, shape_ints, A->pml, rhs, extra, tile_p, tile_t);                                     \
     break;
   switch (G) {
     MK_LAUNCH_S(1)
