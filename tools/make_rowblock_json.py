@@ -16,6 +16,8 @@ keep = ("spmv_sweep_kernel", "offd_", "pack", "finalize_slab", "copyBuffer", "lo
 out = {"what": "rocprofv3 --kernel-trace of tools/dist_probe.py 512 512 512 8: CG on 512^3 as 8 z-slabs (512x512x64 each) driven as a local "
                "world on one GPU (device copies stand in for RCCL, a side stream for the communication stream); kernels launched after the "
                "row blocks were built; probe result in `probe`",
+       "probe_without_profiler": next((l.strip() for l in open(os.path.join(ROOT, "gpurun_out/r02_dist_probe_plain.txt")) if "ms/iteration" in l), None)
+       if os.path.exists(os.path.join(ROOT, "gpurun_out/r02_dist_probe_plain.txt")) else None,
        "probe": next(l.strip() for l in open(os.path.join(ROOT, "gpurun_out/r02_dist_probe.txt")) if "ms/iteration" in l),
        "kernels": {k: {"launches": len(v), "avg_us": round(sum(v) / len(v), 2)} for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1]))
                    if any(t in k for t in keep)}}
