@@ -1220,6 +1220,116 @@ def test_full_size_config2_properties():
     assert np.isclose(true_rel, res["rel_res_norm"], rtol=1e-6)
 
 
+def test_full_size_config3_conversion_is_bit_exact_and_product_matches():
+    """BASELINE config 3 at full size (R-MAT scale 24, 2^28 unsorted entries, duplicates kept): the oracle's counting sort
+    takes a few seconds at this size, so the device conversion is compared with it bit for bit (row pointers, columns in
+    the reference's stable order, value bits), then one product on the 2^24 x 2^24 matrix against the oracle's."""
+    scale, ne = 24, 1 << 28
+    d = mk.DeviceCOO.rmat(scale, ne, seed=42)
+    nr, nc, r, c, v = d.download()
+    assert nr == 1 << scale and r.size == ne
+    A = mk.Matrix.from_device_coo(d)
+    del d
+    rp, ci, val = A.to_csr()
+    orp, oci, ov = oracle.coo_to_csr(nr, r, c, v)
+    del r, c, v
+    assert np.array_equal(rp, orp) and np.array_equal(ci, oci) and _same_bits(val, ov)
+    del rp, ci, val
+    info = A.info()
+    assert info.kernel == mk.SPMV_SPLIT and info.max_row_len > 100000
+    xh = np.random.default_rng(3).normal(size=nc)
+    x, y = mk.Vector(nc, values=xh), mk.Vector(nr)
+    A.spmv(x, y)
+    got = y.get()
+    ref = oracle.csr_spmv(orp, oci, ov, xh)
+    mag = oracle.csr_spmv(orp, oci, np.abs(ov), np.abs(xh))
+    assert (np.abs(got - ref) / np.maximum(mag, 1e-300)).max() <= SPMV_RTOL
+    assert np.count_nonzero(got) == np.count_nonzero(np.diff(orp))      # empty rows give exact zeros, others do not cancel
+    mk.memory_trim()
+
+
+def test_full_size_config4_rank_share_row_sums():
+    """BASELINE config 4, the share of rank 0 of 8 at full size (27-point 512^3, first 64 planes, global column numbers):
+    A * 1 = 26 - (neighbours present), summed over the share = 27 rows - (sum over rows of the 3x3x3 box sizes)"""
+    nx, planes = 512, 64
+    rows = nx * nx * planes
+    A = mk.Matrix.stencil(27, nx, nx, nx, row_begin=0, row_end=rows)
+    assert A.nrows == rows and A.ncols == nx ** 3
+    box = (3 * nx - 2) * (3 * nx - 2) * (3 * planes - 1)      # rank 0 owns the z = 0 boundary only
+    assert A.nnz == box
+    ones, y = mk.Vector(nx ** 3, fill=1.0), mk.Vector(rows)
+    A.spmv(ones, y)
+    yh = y.get()
+    assert yh.sum() == 27.0 * rows - box
+    assert yh.min() == 0.0 and yh[0] == 26.0 - 7.0 and yh[nx * nx + nx + 1] == 0.0
+    del A, ones, y
+    mk.memory_trim()
+
+
+def test_full_size_config5_banded_jacobi_properties():
+    """BASELINE config 5 at full size (banded, half bandwidth 3, 2^26 rows, plain Jacobi): rows further than 3 k from both
+    ends see the same arithmetic whatever n is, so after k sweeps the ends and the interior must equal those of a small
+    oracle run, and the residual norm follows from the small run's per-row residuals."""
+    n, hb, k, m = 1 << 26, 3, 20, 4096
+    rp, ci, v = oracle.banded_csr(m, hb)
+    o = oracle.jacobi(rp, ci, v, np.ones(m), tol=0.0, maxit=k, check_every=10)
+    rp2, ci2, v2 = oracle.banded_csr(2 * m, hb)
+    o2 = oracle.jacobi(rp2, ci2, v2, np.ones(2 * m), tol=0.0, maxit=k, check_every=10)
+    xs = o["x"]
+    A = mk.Matrix.banded(n, hb)
+    b, x = mk.Vector(n, fill=1.0), mk.Vector(n, fill=0.0)
+    S = mk.Jacobi(max_iter=k, tol=0.0, check_every=10)
+    S.setup(A, b, x)
+    res = S.solve(A, b, x)
+    assert res["iterations"] == k == o["iterations"] and res["converged"] == 0
+    xf = x.get()
+    edge = 1024                                   # > hb * k: the ends' influence has not reached row `edge`
+    assert np.allclose(xf[:edge], xs[:edge], rtol=1e-12, atol=0) and np.allclose(xf[-edge:], xs[-edge:], rtol=1e-12, atol=0)
+    mid = xf[edge:n - edge]
+    assert mid.min() == mid.max() and np.isclose(mid[0], xs[m // 2], rtol=1e-12, atol=0)
+    # ||r||^2 = (ends' part) + rows * rho^2 with the same ends' part and interior rho at every n: two small runs give both
+    q1, q2 = o["rel_res_norm"] ** 2 * m, o2["rel_res_norm"] ** 2 * 2 * m
+    rho2 = (q2 - q1) / m
+    expect = np.sqrt((q1 - m * rho2 + n * rho2) / n)
+    assert np.isclose(res["rel_res_norm"], expect, rtol=1e-9)
+    del A, b, x
+    mk.memory_trim()
+
+
+@pytest.mark.parametrize("seed", [None, 3])
+def test_full_size_target_512_cubed_cg_properties(seed):
+    """the target line's operator at full size (7-point 512^3; seed 3: the variable-coefficient form D A D the driver-run
+    roofline is measured on): row sums / symmetry, and CG's recurrence residual equals the true residual b - A x"""
+    nx = 512
+    n = nx ** 3
+    A = mk.Matrix.stencil(7, nx, nx, nx, scale_seed=seed)
+    assert A.nnz == 7 * n - 6 * nx * nx
+    assert A.info().kernel == (mk.SPMV_SWEEP if seed is None else mk.SPMV_VSWEEP)
+    ones, y = mk.Vector(n, fill=1.0), mk.Vector(n)
+    if seed is None:
+        ytx, xtx = A.spmv_dot(ones, y)
+        assert ytx == 6.0 * nx * nx and xtx == float(n)
+    rng = np.random.default_rng(1)
+    u = rng.normal(size=n)
+    U, AU = mk.Vector(n, values=u), mk.Vector(n)
+    A.spmv(U, AU)
+    au = AU.get()
+    A.spmv(ones, y)
+    a1 = y.get()
+    assert abs(au.sum() - u @ a1) <= 1e-11 * (np.abs(u) @ np.abs(a1) + np.abs(au).sum())      # <A u, 1> = <u, A 1>
+    del U, AU, au, a1, u
+    b, x = mk.Vector(n, fill=1.0), mk.Vector(n, fill=0.0)
+    S = mk.PCG(max_iter=30, tol=0.0, precond=0)
+    S.setup(A, b, x)
+    res = S.solve(A, b, x)
+    assert res["iterations"] == 30
+    A.spmv(x, y)
+    true_rel = np.linalg.norm(1.0 - y.get()) / np.sqrt(n)
+    assert np.isclose(true_rel, res["rel_res_norm"], rtol=1e-6)
+    del A, b, x, y, ones, S
+    mk.memory_trim()
+
+
 def test_allocator_keeps_and_reuses_large_blocks():
     """freed device arrays of 1 MB and more wait in the library's free list and serve the next request of their size;
     mk_memory_trim() returns them to the driver (include/mk_krylov.h mk_memory_info / mk_memory_trim)"""
