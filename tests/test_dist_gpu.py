@@ -332,6 +332,39 @@ def test_comm_may_be_destroyed_before_its_matrices():
     del As                                # the last matrix releases the world
 
 
+@pytest.mark.parametrize("kind,nx", [(7, 512), (27, 256)])
+def test_full_size_rowblock_cg_matches_single_matrix(kind, nx):
+    """the 8-GPU target line at full size (7-point 512^3 as 8 slabs of 64 planes; 27-point at 256^3: 512^3 has more entries
+    than one matrix's int32 row pointers hold) driven as a local world: after 30 iterations the residual history equals the
+    single-matrix solve's (other summation order of the inner products: 1e-9), and so does x"""
+    world, iters = 8, 30
+    n = nx ** 3
+    A = mk.Matrix.stencil(kind, nx, nx, nx)
+    b, x = mk.Vector(n, fill=1.0), mk.Vector(n, fill=0.0)
+    S = mk.PCG(max_iter=iters, tol=0.0, precond=1, logging=1, check_every=50)
+    S.setup(A, b, x)
+    one = S.solve(A, b, x)
+    h1 = S.residual_history(iters + 1)
+    x1 = x.get()
+    del A, b, x, S
+    rs = mkd.slab_row_start(nx, nx, nx, world)
+    comms = mkd.Comm.local_world(world)
+    As = [mkd.DistMatrix(mk.Matrix.stencil(kind, nx, nx, nx, row_begin=int(rs[r]), row_end=int(rs[r + 1])), n, rs, comms[r]) for r in range(world)]
+    assert all(a.info()["n_ghost"] == (2 if 0 < r < world - 1 else 1) * nx * nx for r, a in enumerate(As))
+    bs = [a.vector(fill=1.0) for a in As]
+    xs = [a.vector(fill=0.0) for a in As]
+    Ss = [mk.PCG(max_iter=iters, tol=0.0, precond=1, logging=1, check_every=50) for _ in As]
+    res = mkd.dist_pcg_solve(Ss, As, bs, xs)
+    assert all(q == res[0] for q in res) and res[0]["iterations"] == iters == one["iterations"]
+    assert np.isclose(res[0]["rel_res_norm"], one["rel_res_norm"], rtol=1e-9)
+    h8 = Ss[0].residual_history(iters + 1)
+    assert h8.size == h1.size == iters + 1 and np.allclose(h8, h1, rtol=1e-9)
+    x8 = np.concatenate([v.get() for v in xs])
+    assert np.abs(x8 - x1).max() <= 1e-9 * np.abs(x1).max()
+    del As, bs, xs, Ss, comms
+    mk.memory_trim()
+
+
 def test_dist_errors():
     rp, ci, v = oracle.stencil_csr(5, 8, 8)
     comms = mkd.Comm.local_world(2)
