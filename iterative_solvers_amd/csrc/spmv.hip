@@ -26,6 +26,7 @@ struct AnalysisOut {
   unsigned long long hist[16];
   int max_len;
   int min_len;
+  int chunk_max[7];   // most entries in any run of 256 >> k consecutive rows (the stream kernel's chunk with 1 << k lanes per row)
 };
 
 __global__ void analyse_rows_kernel(int64_t nrows, const int *__restrict__ rowptr, AnalysisOut *out) {
@@ -48,6 +49,22 @@ __global__ void analyse_rows_kernel(int64_t nrows, const int *__restrict__ rowpt
   __syncthreads();
   if (threadIdx.x < 16 && sh_hist[threadIdx.x]) atomicAdd(&out->hist[threadIdx.x], (unsigned long long)sh_hist[threadIdx.x]);
   if (threadIdx.x == 0) { atomicMax(&out->max_len, sh_max); atomicMin(&out->min_len, sh_min); }
+}
+
+__global__ void analyse_chunks_kernel(int64_t nrows, const int *__restrict__ rowptr, AnalysisOut *out) {
+  __shared__ int sh[7];
+  if (threadIdx.x < 7) sh[threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, total = (int64_t)gridDim.x * blockDim.x;
+  for (int k = 0; k < 7; k++) {
+    const int R = 256 >> k;
+    const int64_t nch = (nrows + R - 1) / R;
+    int lmax = 0;
+    for (int64_t c = gid; c < nch; c += total) lmax = max(lmax, rowptr[min((c + 1) * R, nrows)] - rowptr[c * R]);
+    if (lmax > 0) atomicMax(&sh[k], lmax);
+  }
+  __syncthreads();
+  if (threadIdx.x < 7 && sh[threadIdx.x] > 0) atomicMax(&out->chunk_max[threadIdx.x], sh[threadIdx.x]);
 }
 
 __global__ void diag_inverse_kernel(int64_t nrows, const int *__restrict__ rowptr, const int *__restrict__ col,
@@ -481,6 +498,7 @@ int analyse_matrix(mk_matrix *A) {
   if (A->nrows > 0) {
     int blocks = (int)std::min<int64_t>((A->nrows + 255) / 256, 2048);
     hipLaunchKernelGGL(analyse_rows_kernel, dim3(blocks), dim3(256), 0, c.stream, A->nrows, A->rowptr, d_out);
+    hipLaunchKernelGGL(analyse_chunks_kernel, dim3(std::min(blocks, 512)), dim3(256), 0, c.stream, A->nrows, A->rowptr, d_out);
   }
   MK_HIP(hipMemcpyAsync(&h, d_out, sizeof(h), hipMemcpyDeviceToHost, c.stream));
   MK_HIP(hipStreamSynchronize(c.stream));
@@ -495,21 +513,26 @@ int analyse_matrix(mk_matrix *A) {
   int lanes = 2;
   while (lanes < 64 && (double)lanes < I.mean_row_len) lanes *= 2;
   if (A->lanes == 0) A->lanes = lanes;
-  // stream kernel: 256/G rows per chunk, G lanes per row in the row pass; usable when the
-  // longest row times the rows per chunk fits the LDS budget (regular matrices)
+  // stream kernel: 256/G rows per chunk, G lanes per row in the row pass; usable when the fullest chunk (the most entries
+  // in any 256/G consecutive rows, measured above -- not rows x longest row, which one long row among short ones inflates)
+  // fits the LDS budget.  G from the mean row length, doubled while the fullest chunk does not fit; a matrix that
+  // needs more than two doublings has rows far longer than its mean and goes to the split kernel.
   int sl = 1;
   static const double env_div = getenv("MK_STREAM_DIV") ? atof(getenv("MK_STREAM_DIV")) : 16.0;
   while (sl < 64 && (double)sl * env_div < I.mean_row_len) sl *= 2;
   static const int env_sl = getenv("MK_STREAM_LANES") ? atoi(getenv("MK_STREAM_LANES")) : 0;   // tuning: 1..64, power of two
   if (env_sl >= 1 && env_sl <= 64 && !(env_sl & (env_sl - 1))) sl = env_sl;
-  while (sl < 64 && (int64_t)(kThreads / sl) * I.max_row_len > kStreamMaxCap) sl *= 2;
+  const int sl_mean = sl;
+  auto fullest = [&](int lanes_) { int k = 0; while ((1 << k) < lanes_) k++; return h.chunk_max[k]; };
+  while (sl < 64 && fullest(sl) > kStreamMaxCap) sl *= 2;
   A->stream_lanes = sl;
-  A->stream_cap = (int)((std::max<int64_t>(64, (int64_t)(kThreads / sl) * I.max_row_len) + 3) & ~(int64_t)3);
-  const bool stream_ok = A->stream_cap <= kStreamMaxCap;
+  A->stream_cap = (int)((std::max<int64_t>(64, fullest(sl)) + 3) & ~(int64_t)3);
+  const bool stream_fits = A->stream_cap <= kStreamMaxCap;
+  const bool stream_ok = stream_fits && sl <= 4 * sl_mean;
   // regular rows -> stream; rows too long for a row-aligned LDS chunk (skewed / power law) -> split
   const bool was_auto = (A->kernel == MK_SPMV_AUTO);
   if (A->kernel == MK_SPMV_AUTO) A->kernel = stream_ok ? MK_SPMV_STREAM : MK_SPMV_SPLIT;
-  if (A->kernel == MK_SPMV_STREAM && !stream_ok) A->kernel = MK_SPMV_SPLIT;
+  if (A->kernel == MK_SPMV_STREAM && !stream_fits) A->kernel = MK_SPMV_SPLIT;
   int64_t longr = 0;
   for (int k = 12; k < 16; k++) longr += I.hist[k];   // rows of 2048 entries or more always cross a chunk border
   I.long_rows = longr;

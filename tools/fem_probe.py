@@ -4,6 +4,7 @@ reference: Bump_2911, Serena, ldoor -- 40-80 entries per row, every entry its ow
 and uploaded as CSR.  Two generators:
   hex3 <nodes_per_side>            3 dof per node on a hexahedral mesh: 27 node neighbours x 3x3 blocks, up to 81 per row
   nine <side>                      2-D 9-point stencil
+  rand3 <nodes> <mean_nb> <halfwin> 3 unknowns per node, random neighbour nodes within +-halfwin, full 3x3 blocks
   rand <rows> <mean_len> <halfwin> row lengths uniform in mean*[2/3,4/3], columns in blocks of 3 anywhere in +-halfwin
 Prints the time of every eligible kernel and the fraction of the CSR byte model (12 nnz + 20 n + 4) over 8 TB/s.
 usage: fem_probe.py [hex3 64 | rand 2000000 45 3000] ...   (several cases may follow each other)"""
@@ -44,6 +45,29 @@ def rand(n, mean, hw):
     ci = np.clip(base - base % 3 + (np.arange(nnz) % 3), 0, n - 1).astype(np.int32)
     ci = ci[np.lexsort((ci, rows))]
     return n, rp.astype(np.int32), ci
+
+
+def rand3(nodes, mean_nb, hw):
+    """3 unknowns per node; every node couples to itself and ~mean_nb random nodes within +-hw, as full 3x3 blocks: the three
+    rows of a node share their column list, no two nodes share a pattern"""
+    rng = np.random.default_rng(2)
+    k = rng.integers(mean_nb * 2 // 3, mean_nb * 4 // 3 + 1, nodes)
+    src = np.repeat(np.arange(nodes), k)
+    dst = np.clip(src + rng.integers(-hw, hw + 1, src.size), 0, nodes - 1)
+    pairs = np.unique(np.concatenate([src, np.arange(nodes)]) * nodes + np.concatenate([dst, np.arange(nodes)]))   # sorted, no duplicates, diagonal in
+    src, dst = pairs // nodes, pairs % nodes
+    cnt = np.bincount(src, minlength=nodes)                     # node neighbours per node
+    nrp = np.concatenate([[0], np.cumsum(cnt)])
+    # row 3 i + d holds, for every neighbour node j in order, columns 3 j, 3 j + 1, 3 j + 2
+    rows_len = np.repeat(cnt * 3, 3)
+    rp = np.concatenate([[0], np.cumsum(rows_len)]).astype(np.int64)
+    node_cols = (dst[:, None] * 3 + np.arange(3)[None, :]).reshape(-1)          # per node: its column list
+    lists = [node_cols[3 * nrp[i]:3 * nrp[i + 1]] for i in range(0)]            # (kept for clarity; built vectorised below)
+    idx = np.repeat(np.arange(nodes), 3)                                        # row -> node
+    starts = 3 * nrp[idx]
+    take = np.repeat(starts, rows_len) + (np.arange(rp[-1]) - np.repeat(rp[:-1], rows_len))
+    ci = node_cols[take].astype(np.int32)
+    return 3 * nodes, rp.astype(np.int32), ci
 
 
 def run(name, n, rp, ci):
@@ -92,6 +116,8 @@ mk.init(0)
 while args:
     if args[0] == "nine":
         run(f"nine {args[1]}", *nine(int(args[1]))); args = args[2:]
+    elif args[0] == "rand3":
+        run(f"rand3 {args[1]} {args[2]} {args[3]}", *rand3(int(args[1]), int(args[2]), int(args[3]))); args = args[4:]
     elif args[0] == "hex3":
         run(f"hex3 {args[1]}", *hex3(int(args[1]))); args = args[2:]
     else:
