@@ -118,6 +118,8 @@ typedef struct {
                               (lossless; the stream kernel then reads 2 B per row instead of 4 B per entry) */
   int64_t value_patterns;  /* > 0: the rows of a pattern also share their values bit for bit (constant-coefficient
                               operators); MK_SPMV_PATTERN then serves offsets AND values from the table */
+  int32_t stream_lanes;    /* MK_SPMV_STREAM: lanes per row; a chunk is 256 / stream_lanes consecutive rows */
+  int32_t stream_chunk;    /* ... and the entries of its fullest chunk (what the kernel stages in LDS) */
 } mk_matrix_info;
 int mk_matrix_get_info(const mk_matrix *A, mk_matrix_info *info);
 

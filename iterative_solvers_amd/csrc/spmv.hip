@@ -19,7 +19,12 @@
 namespace mk {
 
 constexpr int kThreads = 256;
-constexpr int kStreamMaxCap = 3064;   // LDS entries per block (12 B each): 36 KB -> 4 blocks per CU
+// LDS entries per block (12 B each, 48 KB at most -> three blocks per CU); MK_STREAM_MAX_CAP lowers it (3064: the limit until r02)
+static int stream_max_cap() {
+  static const int v = getenv("MK_STREAM_MAX_CAP") ? std::max(64, std::min(atoi(getenv("MK_STREAM_MAX_CAP")), 4088)) : 4088;
+  return v;
+}
+#define kStreamMaxCap stream_max_cap()
 
 // ------------------------------------------------------------------ matrix analysis
 struct AnalysisOut {
@@ -536,6 +541,8 @@ int analyse_matrix(mk_matrix *A) {
   int64_t longr = 0;
   for (int k = 12; k < 16; k++) longr += I.hist[k];   // rows of 2048 entries or more always cross a chunk border
   I.long_rows = longr;
+  I.stream_lanes = A->stream_lanes;
+  I.stream_chunk = A->stream_cap;
   I.kernel = A->kernel;
   I.lanes_per_row = A->lanes;
   I.index_patterns = 0;
@@ -929,6 +936,7 @@ static int launch_stream(const mk_matrix *A, double alpha, const double *x, doub
   MK_STREAM_PICK(1)
   MK_STREAM_PICK(2)
   MK_STREAM_PICK(3)
+  MK_STREAM_PICK(4)
 #undef MK_STREAM_PICK
   return fail(MK_ERR_UNSUPPORTED, "spmv: stream capacity %d too large", cap);
 }

@@ -673,6 +673,8 @@ def test_spmv_stream_long_rows():
     A = mk.Matrix.from_csr(n, n, rp, ci, v)
     i = A.info()
     assert i.kernel == mk.SPMV_STREAM and i.max_row_len == 81 and 81 <= i.index_patterns <= 2048
+    fullest = np.add.reduceat(np.diff(rp), np.arange(0, n, 32)).max()
+    assert i.stream_lanes == 8 and i.stream_chunk == (fullest + 3) // 4 * 4   # lanes from the mean row length, chunk = 32 rows
     _check_spmv(A, rp, ci, v, n, n, rng)
     _check_spmv(A, rp, ci, v, n, n, rng, alpha=-0.3, beta=2.0)
     # b) irregular: 60..95 random columns per row, no two rows alike -> col[] is read
@@ -686,6 +688,8 @@ def test_spmv_stream_long_rows():
     v2 = rng.normal(size=rp2[-1])
     B = mk.Matrix.from_csr(n2, n2, rp2, ci2, v2)
     assert B.info().kernel == mk.SPMV_STREAM and B.info().index_patterns == 0
+    lens32 = np.add.reduceat(lens, np.arange(0, n2, 32))
+    assert B.info().stream_lanes == 8 and B.info().stream_chunk == (lens32.max() + 3) // 4 * 4   # the fullest run of 32 rows, not 32 x 95
     _check_spmv(B, rp2, ci2, v2, n2, n2, rng, alpha=1.25, beta=-0.5)
     yx, xx = None, None
     xh = rng.normal(size=n2)
