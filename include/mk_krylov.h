@@ -120,6 +120,8 @@ typedef struct {
                               operators); MK_SPMV_PATTERN then serves offsets AND values from the table */
   int32_t stream_lanes;    /* MK_SPMV_STREAM: lanes per row; a chunk is 256 / stream_lanes consecutive rows */
   int32_t stream_chunk;    /* ... and the entries of its fullest chunk (what the kernel stages in LDS) */
+  int64_t shared_columns;  /* > 0: that many entries sit in rows that repeat the column list of the row before them (several
+                              unknowns per mesh node); MK_SPMV_STREAM reads such a list once (lossless, same order) */
 } mk_matrix_info;
 int mk_matrix_get_info(const mk_matrix *A, mk_matrix_info *info);
 

@@ -144,6 +144,9 @@ struct mk_matrix {
   int *ptab = nullptr;             // npat x (pml+1) ints: length, offsets
   int *stab = nullptr;             // stream kernel's two-level copy when patterns share shapes: [shapes: length, offsets - first offset][npat x (shape start, first offset)]
   int stab_shape_ints = 0, stab_ints = 0;
+  int *colc = nullptr;             // stream kernel, rows that repeat the column list of the row before them (the unknowns of one mesh node):
+  int *cptr = nullptr;             // colc = the lists stored once, cptr[row] = where row's list starts in colc
+  int64_t colc_len = 0;
   double *vtab = nullptr;          // npat x pml doubles when the rows of a pattern also share their values
                                    // (pattern kernel: neither col[] nor val[] nor rowptr[] is read)
   int *otab8 = nullptr;            // pattern kernel's padded copies of ptab / vtab (row stride p8 + 8 ints, p8 doubles)

@@ -492,6 +492,81 @@ static int try_compress(mk_matrix *A) {
   return MK_OK;
 }
 
+// ------------------------------------------------------------- shared column lists
+// In a finite-element matrix with several unknowns per mesh node the rows of a node carry the same column list.  Rows whose
+// list equals that of the row before them are marked, the lists are stored once (colc) and every row gets the start of the
+// list it uses (cptr): the stream kernel then stages 4 B per entry of every third row only.  Lossless: same (column, value)
+// pairs in the same order; col[] stays for mk_matrix_get_csr and the other kernels.
+__global__ void share_mark_kernel(int64_t nrows, const int *__restrict__ rowptr, const int *__restrict__ col, uint32_t *__restrict__ w,
+                                  unsigned long long *__restrict__ saved) {
+  unsigned long long mine = 0;
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += (int64_t)gridDim.x * blockDim.x) {
+    const int b = rowptr[r], len = rowptr[r + 1] - b;
+    bool same = false;
+    if (r > 0 && len > 0) {
+      const int pb = rowptr[r - 1];
+      if (b - pb == len) {
+        same = true;
+        for (int k = 0; k < len; k++)
+          if (col[pb + k] != col[b + k]) { same = false; break; }
+      }
+    }
+    w[r] = same ? 0u : (uint32_t)len;
+    if (same) mine += (unsigned long long)len;
+  }
+  for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off, 64);
+  if ((threadIdx.x & 63) == 0 && mine) atomicAdd(saved, mine);
+}
+
+__global__ void share_build_kernel(int64_t nrows, const int *__restrict__ rowptr, const int *__restrict__ col, const uint32_t *__restrict__ w,
+                                   const uint32_t *__restrict__ scan, int *__restrict__ cptr, int *__restrict__ colc) {
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += (int64_t)gridDim.x * blockDim.x) {
+    const int b = rowptr[r], len = rowptr[r + 1] - b;
+    if (w[r] != 0u) {
+      const int at = (int)scan[r];
+      cptr[r] = at;
+      for (int k = 0; k < len; k++) colc[at + k] = col[b + k];
+    } else {
+      cptr[r] = (int)scan[r] - len;   // the list of the row before (its own start when the row is empty)
+    }
+  }
+}
+
+static int try_share_columns(mk_matrix *A) {
+  static const int off = getenv("MK_NO_SHARED_COLUMNS") ? atoi(getenv("MK_NO_SHARED_COLUMNS")) : 0;
+  if (off || A->pat || A->colc || A->nrows < 2 || A->nnz < 1 || A->info.mean_row_len < 12.0) return MK_OK;
+  Context &c = ctx();
+  uint32_t *w = nullptr, *scan = nullptr;
+  unsigned long long *saved = nullptr, h_saved = 0;
+  MK_TRY(dev_alloc(&w, (size_t)A->nrows));
+  MK_TRY(dev_alloc(&scan, (size_t)A->nrows));
+  MK_TRY(dev_alloc(&saved, 1));
+  MK_HIP(hipMemsetAsync(saved, 0, sizeof(unsigned long long), c.stream));
+  const int blocks = (int)std::min<int64_t>((A->nrows + 255) / 256, 4096);
+  hipLaunchKernelGGL(share_mark_kernel, dim3(blocks), dim3(256), 0, c.stream, A->nrows, A->rowptr, A->col, w, saved);
+  MK_HIP(hipMemcpyAsync(&h_saved, saved, sizeof(h_saved), hipMemcpyDeviceToHost, c.stream));
+  MK_HIP(hipStreamSynchronize(c.stream));
+  int rc = MK_OK;
+  if ((double)h_saved >= 0.4 * (double)A->nnz) {   // pays from two rows in five repeating their neighbour
+    const int64_t keep = A->nnz - (int64_t)h_saved;
+    rc = exclusive_scan_u32(w, scan, (size_t)A->nrows, nullptr);
+    if (rc == MK_OK) rc = dev_alloc(&A->cptr, (size_t)A->nrows);
+    if (rc == MK_OK) rc = dev_alloc(&A->colc, (size_t)keep + 4);
+    if (rc == MK_OK) {
+      MK_HIP(hipMemsetAsync(A->colc + keep, 0, 4 * sizeof(int), c.stream));   // the tail a 16-byte load may touch
+      hipLaunchKernelGGL(share_build_kernel, dim3(blocks), dim3(256), 0, c.stream, A->nrows, A->rowptr, A->col, w, scan, A->cptr, A->colc);
+      MK_HIP(hipStreamSynchronize(c.stream));
+      A->colc_len = keep;
+    } else {
+      dev_free(A->cptr); dev_free(A->colc);
+      A->cptr = nullptr; A->colc = nullptr;
+      rc = MK_OK;   // an optimisation only
+    }
+  }
+  dev_free(w); dev_free(scan); dev_free(saved);
+  return rc;
+}
+
 int analyse_matrix(mk_matrix *A) {
   if (A->analysed) return MK_OK;
   Context &c = ctx();
@@ -549,6 +624,7 @@ int analyse_matrix(mk_matrix *A) {
   if (A->kernel == MK_SPMV_STREAM) {
     MK_TRY(try_compress<true>(A));                 // offsets and values shared by rows -> pattern kernel
     if (!A->pat) MK_TRY(try_compress<false>(A));   // offsets only -> stream kernel without col[]
+    if (!A->pat) MK_TRY(try_share_columns(A));     // rows repeating their neighbour's column list -> lists stored once
     if (A->vtab && was_auto) A->kernel = (A->sweep && A->sweep_auto) ? MK_SPMV_SWEEP : MK_SPMV_PATTERN;
     static const int no_vsweep = getenv("MK_NO_VSWEEP") ? atoi(getenv("MK_NO_VSWEEP")) : 0;
     if (!A->vtab && A->pat && A->sweep && A->sweep_streamed && A->sweep_auto && was_auto && !no_vsweep) A->kernel = MK_SPMV_VSWEEP;
@@ -556,6 +632,7 @@ int analyse_matrix(mk_matrix *A) {
   I.kernel = A->kernel;
   I.index_patterns = A->pat ? A->npat : 0;
   I.value_patterns = A->vtab ? A->npat : 0;
+  I.shared_columns = A->cptr ? A->nnz - A->colc_len : 0;
   A->analysed = true;
   return MK_OK;
 }
@@ -718,8 +795,17 @@ __global__ __launch_bounds__(kThreads) void spmv_stream_kernel(
   int64_t chunk = next_chunk(q);
   int cb = 0, ce = 0;
   int64_t r0 = 0, r1 = 0;
-  auto stage_loads = [&](int cb_, int ce_) {
-    const int vb_ = cb_ & ~1, ib_ = cb_ & ~3;
+  // shared column lists (try_share_columns): without a pattern table the ptab argument carries cptr, col is the compact
+  // array, and the chunk's column span is [cptr[first row], end of the last row's list) instead of the value span
+  const int *cptr = COMP ? nullptr : ptab;
+  int ccb = 0, cce = 0;
+  auto col_span = [&](int64_t r0_, int64_t r1_, int cb_, int ce_, int &ccb_, int &cce_) {
+    if (COMP || cptr == nullptr) { ccb_ = cb_; cce_ = ce_; return; }
+    ccb_ = cptr[r0_];
+    cce_ = cptr[r1_ - 1] + (ce_ - rowptr[r1_ - 1]);
+  };
+  auto stage_loads = [&](int cb_, int ce_, int ccb_, int cce_) {
+    const int vb_ = cb_ & ~1, ib_ = ccb_ & ~3;
 #pragma unroll
     for (int i = 0; i < NV; i++) {
       const int k = vb_ + (tid + i * kThreads) * 2;
@@ -728,7 +814,7 @@ __global__ __launch_bounds__(kThreads) void spmv_stream_kernel(
 #pragma unroll
     for (int i = 0; i < NI; i++) {
       const int k = ib_ + (tid + i * kThreads) * 4;
-      if (k < ce_) ri[i] = NT ? __builtin_nontemporal_load(reinterpret_cast<const i4_t *>(col + k)) : *reinterpret_cast<const i4_t *>(col + k);
+      if (k < cce_) ri[i] = NT ? __builtin_nontemporal_load(reinterpret_cast<const i4_t *>(col + k)) : *reinterpret_cast<const i4_t *>(col + k);
     }
     (void)ib_;
   };
@@ -737,10 +823,11 @@ __global__ __launch_bounds__(kThreads) void spmv_stream_kernel(
     r1 = min(r0 + R, nrows);
     cb = rowptr[r0];
     ce = rowptr[r1];
-    stage_loads(cb, ce);
+    col_span(r0, r1, cb, ce, ccb, cce);
+    stage_loads(cb, ce, ccb, cce);
   }
   while (chunk < last) {
-    const int vb = cb & ~1, ib = cb & ~3;
+    const int vb = cb & ~1, ib = ccb & ~3;
 #pragma unroll
     for (int i = 0; i < NV; i++) {
       const int k = vb + (tid + i * kThreads) * 2;
@@ -749,12 +836,12 @@ __global__ __launch_bounds__(kThreads) void spmv_stream_kernel(
 #pragma unroll
     for (int i = 0; i < NI; i++) {
       const int k = ib + (tid + i * kThreads) * 4;
-      if (k < ce) *reinterpret_cast<i4_t *>(scol + (k - ib)) = ri[i];
+      if (k < cce) *reinterpret_cast<i4_t *>(scol + (k - ib)) = ri[i];
     }
     const int64_t row = r0 + rl;
     const bool have_row = row < r1;
-    int b = 0, e = 0, pid = 0;
-    if (have_row) { b = rowptr[row] - cb; e = rowptr[row + 1] - cb; }
+    int b = 0, e = 0, pid = 0, cstart = ccb;
+    if (have_row) { b = rowptr[row] - cb; e = rowptr[row + 1] - cb; cstart = (!COMP && cptr) ? cptr[row] : cb + b; }
     if (COMP && have_row) pid = NT ? __builtin_nontemporal_load(pat + row) : pat[row];
     __syncthreads();
     const double *sv = sval + (cb - vb);
@@ -763,7 +850,7 @@ __global__ __launch_bounds__(kThreads) void spmv_stream_kernel(
       pbase = scol[shape_ints + 2 * pid];
       pshift = scol[shape_ints + 2 * pid + 1];
     }
-    const int *sc = COMP ? scol + pbase + 1 - b : scol + (cb - ib);   // sc[j]: column (or column - row - shift) of entry j
+    const int *sc = COMP ? scol + pbase + 1 - b : scol + (cstart - ib) - b;   // sc[j]: column (or column - row - shift) of entry j
     const int cadd = COMP ? (int)row + pshift : 0;
     // first 8 entries of the row (per lane): all gathers issued before anything waits
     const int lastj = max(e - 1, 0);
@@ -785,14 +872,15 @@ __global__ __launch_bounds__(kThreads) void spmv_stream_kernel(
     // prefetch the next chunk (stays in flight while this one is reduced)
     q += slots;
     const int64_t next = next_chunk(q);
-    int ncb = 0, nce = 0;
+    int ncb = 0, nce = 0, nccb = 0, ncce = 0;
     int64_t nr0 = 0, nr1 = 0;
     if (next < last) {
       nr0 = next * R;
       nr1 = min(nr0 + R, nrows);
       ncb = rowptr[nr0];
       nce = rowptr[nr1];
-      stage_loads(ncb, nce);
+      col_span(nr0, nr1, ncb, nce, nccb, ncce);
+      stage_loads(ncb, nce, nccb, ncce);
     }
     double sum = 0.0, dv = 0.0;
     int dj = -1;
@@ -847,7 +935,7 @@ __global__ __launch_bounds__(kThreads) void spmv_stream_kernel(
       if (NT) __builtin_nontemporal_store(yv, y + row); else y[row] = yv;
     }
     __syncthreads();
-    chunk = next; cb = ncb; ce = nce; r0 = nr0; r1 = nr1;
+    chunk = next; cb = ncb; ce = nce; ccb = nccb; cce = ncce; r0 = nr0; r1 = nr1;
   }
   if (MODE != 0) {
     double *red = reinterpret_cast<double *>(smem_raw);
@@ -867,7 +955,9 @@ static int launch_stream_u(const mk_matrix *A, double alpha, const double *x, do
   const int G = A->stream_lanes, cap = A->stream_cap;
   const bool shapes = COMP && A->stab != nullptr;
   const int tab_ints = COMP ? (shapes ? A->stab_ints : A->npat * (A->pml + 1)) : 0;
-  const int *table = shapes ? A->stab : A->ptab;
+  const bool shared_cols = !COMP && A->cptr != nullptr;
+  const int *table = COMP ? (shapes ? A->stab : A->ptab) : (shared_cols ? A->cptr : nullptr);
+  const int *colv = shared_cols ? A->colc : A->col;
   const int shape_ints = shapes ? A->stab_shape_ints : 0;
   const size_t lds = (size_t)(cap + 2) * 8 + (COMP ? (size_t)tab_ints * 4 + 16 : (size_t)(cap + 8) * 4);  // cap is a multiple of 4
   const int64_t nchunks = (A->nrows + (kThreads / G) - 1) / (kThreads / G);
@@ -901,7 +991,7 @@ static int launch_stream_u(const mk_matrix *A, double alpha, const double *x, do
 #define MK_LAUNCH_S(GG)                                                                                            \
   case GG:                                                                                                         \
     hipLaunchKernelGGL((spmv_stream_kernel<GG, MODE, U, COMP, NT>), dim3((unsigned)blocks), dim3(kThreads), lds,      \
-                       c.stream, A->nrows, A->rowptr, A->col, A->val, x, y, alpha, beta, slab, done, cap, A->pat,  \
+                       c.stream, A->nrows, A->rowptr, colv, A->val, x, y, alpha, beta, slab, done, cap, A->pat,      \
                        table, tab_ints, shape_ints, A->pml, rhs, extra, tile_p, tile_t);                                     \
     break;
   switch (G) {

@@ -697,6 +697,44 @@ def test_spmv_stream_long_rows():
     yx, xx = B.spmv_dot(x, y)
     ref = oracle.csr_spmv(rp2, ci2, v2, xh)
     assert np.isclose(yx, ref @ xh, rtol=1e-11, atol=1e-9) and np.isclose(xx, xh @ xh, rtol=1e-12)
+    # b2) node blocks: three rows per node with one (random) column list, no two nodes alike -> the list is staged once
+    nodes = 1700
+    nb = [np.unique(np.concatenate([[i], rng.integers(max(0, i - 40), min(nodes, i + 41), int(rng.integers(8, 30)))])) for i in range(nodes)]
+    if True:
+        nb[5] = nb[4].copy()            # two neighbouring nodes with the same list: six rows share it
+        nb[7] = np.array([7])           # a node coupled to itself only
+    lists = [(np.repeat(q * 3, 3) + np.tile(np.arange(3), q.size)).astype(np.int32) for q in nb]
+    ci3 = np.concatenate([np.tile(l, 3) for l in lists]).astype(np.int32)
+    lens3 = np.repeat([l.size for l in lists], 3)
+    # rows 3 i + 1 of every 11th node drop their last entry: same length class broken, list not shared with its neighbours
+    n3 = 3 * nodes
+    rp3 = np.concatenate([[0], np.cumsum(lens3)]).astype(np.int32)
+    keep = np.ones(ci3.size, bool)
+    for i in range(0, nodes, 11):
+        if lists[i].size > 3:
+            keep[rp3[3 * i + 2] - 1] = False      # last entry of row 3 i + 1
+            lens3[3 * i + 1] -= 1
+    ci3 = ci3[keep]
+    rp3 = np.concatenate([[0], np.cumsum(lens3)]).astype(np.int32)
+    v3 = rng.normal(size=ci3.size)
+    C3 = mk.Matrix.from_csr(n3, n3, rp3, ci3, v3)
+    i3 = C3.info()
+    assert i3.kernel == mk.SPMV_STREAM and i3.index_patterns == 0
+    same = np.zeros(n3, bool)
+    for r in range(1, n3):
+        a, b_ = ci3[rp3[r - 1]:rp3[r]], ci3[rp3[r]:rp3[r + 1]]
+        same[r] = a.size == b_.size and b_.size > 0 and np.array_equal(a, b_)
+    assert i3.shared_columns == int(lens3[same].sum()) and i3.shared_columns > 0.55 * ci3.size
+    _check_spmv(C3, rp3, ci3, v3, n3, n3, rng)
+    _check_spmv(C3, rp3, ci3, v3, n3, n3, rng, alpha=0.5, beta=1.5)
+    xh3 = rng.normal(size=n3)
+    x3, y3 = mk.Vector(n3, values=xh3), mk.Vector(n3)
+    C3.spmv(x3, y3)
+    shared_result = y3.get()
+    yx3, xx3 = C3.spmv_dot(x3, y3)
+    assert np.array_equal(y3.get(), shared_result) and np.isclose(yx3, shared_result @ xh3, rtol=1e-11, atol=1e-9)
+    rp_b, ci_b, v_b = C3.to_csr()
+    assert np.array_equal(rp_b, rp3) and np.array_equal(ci_b, ci3) and _same_bits(v_b, v3)     # the CSR arrays stay as given
     # c) Jacobi on a): the sweep picks the diagonal out of the row as it goes by, also from the tail batch
     vd = v.copy()
     absum = np.bincount(rows, weights=np.abs(v), minlength=n)
