@@ -5,6 +5,7 @@ and uploaded as CSR.  Two generators:
   hex3 <nodes_per_side>            3 dof per node on a hexahedral mesh: 27 node neighbours x 3x3 blocks, up to 81 per row
   nine <side>                      2-D 9-point stencil
   rand3 <nodes> <mean_nb> <halfwin> 3 unknowns per node, random neighbour nodes within +-halfwin, full 3x3 blocks
+  skew <rows> <mean_len> <every> <long_len>  short rows with one long row every so many rows
   rand <rows> <mean_len> <halfwin> row lengths uniform in mean*[2/3,4/3], columns in blocks of 3 anywhere in +-halfwin
 Prints the time of every eligible kernel and the fraction of the CSR byte model (12 nnz + 20 n + 4) over 8 TB/s.
 usage: fem_probe.py [hex3 64 | rand 2000000 45 3000] ...   (several cases may follow each other)"""
@@ -70,6 +71,19 @@ def rand3(nodes, mean_nb, hw):
     return 3 * nodes, rp.astype(np.int32), ci
 
 
+def skew(n, mean, every, long_len):
+    """short rows (about `mean` entries near the diagonal) with one row of `long_len` entries every `every` rows: the shape of
+    circuit matrices (scircuit, hvdc1/2 of the authors' list)"""
+    rng = np.random.default_rng(3)
+    lens = rng.integers(max(1, mean // 2), mean * 3 // 2 + 1, n)
+    lens[::every] = long_len
+    rp = np.concatenate([[0], np.cumsum(lens)])
+    rows = np.repeat(np.arange(n), lens)
+    ci = np.clip(rows + rng.integers(-2000, 2001, rows.size), 0, n - 1).astype(np.int32)
+    ci = ci[np.lexsort((ci, rows))]
+    return n, rp.astype(np.int32), ci
+
+
 def run(name, n, rp, ci):
     nnz = ci.size
     v = np.random.default_rng(0).normal(size=nnz)
@@ -116,6 +130,8 @@ mk.init(0)
 while args:
     if args[0] == "nine":
         run(f"nine {args[1]}", *nine(int(args[1]))); args = args[2:]
+    elif args[0] == "skew":
+        run(f"skew {args[1]} {args[2]} {args[3]} {args[4]}", *skew(*(int(a) for a in args[1:5]))); args = args[5:]
     elif args[0] == "rand3":
         run(f"rand3 {args[1]} {args[2]} {args[3]}", *rand3(int(args[1]), int(args[2]), int(args[3]))); args = args[4:]
     elif args[0] == "hex3":
