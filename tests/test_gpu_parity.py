@@ -759,6 +759,29 @@ def test_spmv_on_golden_matrices(name):
     _check_spmv(A, g["csr_rowptr"], g["csr_col"], g["csr_val"], n, nc, np.random.default_rng(1))
 
 
+def test_selector_long_row_among_short_ones():
+    """short rows with a few long ones: the chunk capacity would fit the stream kernel, the rows of more than 32 entries per
+    lane send the matrix to the split kernel; without them it stays on the stream kernel (both against the oracle)"""
+    rng = np.random.default_rng(31)
+    n = 20000
+    for long_len, expect in ((400, mk.SPMV_SPLIT), (0, mk.SPMV_STREAM)):
+        lens = rng.integers(3, 10, n)
+        if long_len:
+            lens[777::5000] = long_len
+        rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        rows = np.repeat(np.arange(n), lens)
+        ci = rng.integers(0, n, rp[-1])
+        ci = ci[np.lexsort((ci, rows))].astype(np.int32)
+        v = rng.normal(size=rp[-1])
+        A = mk.Matrix.from_csr(n, n, rp, ci, v)
+        i = A.info()
+        assert i.kernel == expect and i.stream_lanes == 1 and i.stream_chunk <= 4088
+        _check_spmv(A, rp, ci, v, n, n, rng, alpha=2.0, beta=-0.5)
+        if long_len:                       # the stream kernel still serves it when asked to
+            A.set_spmv_kernel(mk.SPMV_STREAM)
+            _check_spmv(A, rp, ci, v, n, n, rng)
+
+
 def test_spmv_skewed_rows_rmat():
     scale, ne = 14, 1 << 18
     r, c, v = oracle.rmat_coo(scale, ne)
