@@ -1783,6 +1783,9 @@ __global__ void split_chunk_rows_kernel(int64_t nrows, int64_t nnz, const int *_
   }
 }
 
+#ifndef MK_LONG_PIECE
+#define MK_LONG_PIECE 64
+#endif
 template <int MODE, bool NT>   // NT: the matrix does not fit the Infinity Cache, it streams past nontemporally and the caches keep x
 __global__ __launch_bounds__(kThreads) void spmv_split_kernel(
     int64_t nrows, int64_t nnz, const int *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ val,
@@ -1792,11 +1795,17 @@ __global__ __launch_bounds__(kThreads) void spmv_split_kernel(
   if (done != nullptr && *done != 0) return;
   __shared__ __attribute__((aligned(16))) double prod[kSplitChunk];
   __shared__ double red[2 * (kThreads / 64)];
+  // pieces of more than kLongPiece entries per lane are left to a whole wave each (second part of pass 2): a 1200-entry row among
+  // 140 short ones would otherwise be summed by ONE lane, ~80 clocks per LDS read, while the block waits (measured with fem_probe.py skew)
+  constexpr int kLongPiece = MK_LONG_PIECE, kLongMax = kSplitChunk / kLongPiece;
+  __shared__ int long_q[kLongMax], long_s[kLongMax];
+  __shared__ int long_n;
   const int tid = threadIdx.x;
   double acc_yx = 0.0, acc_xx = 0.0;
   for (int c = blockIdx.x; c < nchunks; c += gridDim.x) {
     const int64_t e0 = (int64_t)c * kSplitChunk;
     const int64_t e1 = min(e0 + kSplitChunk, nnz);
+    if (tid == 0) long_n = 0;   // read again only behind the barrier that follows pass 1
     // pass 1
 #pragma unroll
     for (int i = 0; i < kSplitChunk / (2 * kThreads); i++) {
@@ -1830,6 +1839,10 @@ __global__ __launch_bounds__(kThreads) void spmv_split_kernel(
         t_r = NT ? __builtin_nontemporal_load(rowptr + r + 1) : rowptr[r + 1];
         sb = entering ? e0 : (int64_t)(NT ? __builtin_nontemporal_load(rowptr + r) : rowptr[r]);
         se = min(t_r, e1);
+        if (se - sb > (int64_t)kLongPiece * lp) {          // uniform over the lp lanes of the row
+          if (g == 0) long_q[atomicAdd(&long_n, 1)] = q;   // at most kSplitChunk / (kLongPiece + 1) such pieces in a chunk
+          continue;
+        }
         for (int64_t j = sb + g; j < se; j += lp) sum += prod[j - e0];
       }
       for (int off = lp >> 1; off > 0; off >>= 1) sum += __shfl_down(sum, off, lp);
@@ -1853,6 +1866,47 @@ __global__ __launch_bounds__(kThreads) void spmv_split_kernel(
       }
     }
     __syncthreads();
+    const int nl = long_n;                                        // the same in every thread
+    if (nl > 0) {
+      if (tid < nl) {                                             // list order = order of arrival: sort it (rank of each key), so that
+        const int key = long_q[tid];                              // which wave sums which row (and adds to which partial of the dots) is fixed
+        int rank = 0;
+        for (int k = 0; k < nl; k++) rank += (long_q[k] < key);
+        long_s[rank] = key;
+      }
+      __syncthreads();
+      const int lane = tid & 63;
+      for (int k = tid >> 6; k < nl; k += kThreads / 64) {
+        const int q = long_s[k];
+        const bool entering = (q == 0);
+        const int r = entering ? rs - 1 : rs + q - 1;
+        const int64_t t_r = rowptr[r + 1];
+        const int64_t sb = entering ? e0 : (int64_t)rowptr[r];
+        const int64_t se = min(t_r, e1);
+        double sum = 0.0;
+        for (int64_t j = sb + lane; j < se; j += 64) sum += prod[j - e0];
+        for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
+        if (lane == 0) {
+          if (entering) {
+            carry[2 * c] = sum;
+          } else if (t_r <= e1) {
+            if (MODE == 0) {
+              const double yv = (beta == 0.0) ? alpha * sum : alpha * sum + beta * y[r];
+              if (NT) __builtin_nontemporal_store(yv, y + r); else y[r] = yv;
+            } else {
+              if (NT) __builtin_nontemporal_store(sum, y + r); else y[r] = sum;
+              const double xr = x[r];
+              acc_yx += sum * xr;
+              acc_xx += xr * xr;
+            }
+          } else {
+            carry[2 * c + 1] = sum;
+            if (MODE == 1) { const double xr = x[r]; acc_xx += xr * xr; }
+          }
+        }
+      }
+      __syncthreads();
+    }
   }
   if (MODE == 1) {
     double v[2] = {acc_yx, acc_xx};
