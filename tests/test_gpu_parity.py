@@ -777,6 +777,12 @@ def test_selector_long_row_among_short_ones():
         i = A.info()
         assert i.kernel == expect and i.stream_lanes == 1 and i.stream_chunk <= 4088
         _check_spmv(A, rp, ci, v, n, n, rng, alpha=2.0, beta=-0.5)
+        xh = rng.normal(size=n)
+        x, y = mk.Vector(n, values=xh), mk.Vector(n)
+        yx, xx = A.spmv_dot(x, y)          # split kernel: the long rows are summed by a wave each, also for the fused dots
+        ref = oracle.csr_spmv(rp, ci, v, xh)
+        assert np.allclose(y.get(), ref, rtol=1e-11, atol=1e-11) and np.isclose(yx, ref @ xh, rtol=1e-10, atol=1e-9) and np.isclose(xx, xh @ xh, rtol=1e-12)
+        assert (yx, xx) == A.spmv_dot(x, y)                                  # and the same bits every time
         if long_len:                       # the stream kernel still serves it when asked to
             A.set_spmv_kernel(mk.SPMV_STREAM)
             _check_spmv(A, rp, ci, v, n, n, rng)
