@@ -700,9 +700,8 @@ def test_spmv_stream_long_rows():
     # b2) node blocks: three rows per node with one (random) column list, no two nodes alike -> the list is staged once
     nodes = 1700
     nb = [np.unique(np.concatenate([[i], rng.integers(max(0, i - 40), min(nodes, i + 41), int(rng.integers(8, 30)))])) for i in range(nodes)]
-    if True:
-        nb[5] = nb[4].copy()            # two neighbouring nodes with the same list: six rows share it
-        nb[7] = np.array([7])           # a node coupled to itself only
+    nb[5] = nb[4].copy()                # two neighbouring nodes with the same list: six rows share it
+    nb[7] = np.array([7])               # a node coupled to itself only
     lists = [(np.repeat(q * 3, 3) + np.tile(np.arange(3), q.size)).astype(np.int32) for q in nb]
     ci3 = np.concatenate([np.tile(l, 3) for l in lists]).astype(np.int32)
     lens3 = np.repeat([l.size for l in lists], 3)

@@ -63,7 +63,6 @@ def rand3(nodes, mean_nb, hw):
     rows_len = np.repeat(cnt * 3, 3)
     rp = np.concatenate([[0], np.cumsum(rows_len)]).astype(np.int64)
     node_cols = (dst[:, None] * 3 + np.arange(3)[None, :]).reshape(-1)          # per node: its column list
-    lists = [node_cols[3 * nrp[i]:3 * nrp[i + 1]] for i in range(0)]            # (kept for clarity; built vectorised below)
     idx = np.repeat(np.arange(nodes), 3)                                        # row -> node
     starts = 3 * nrp[idx]
     take = np.repeat(starts, rows_len) + (np.arange(rp[-1]) - np.repeat(rp[:-1], rows_len))
