@@ -3,6 +3,7 @@
 // driven once through the C ABI.  Checks host heap use only; device code is not instrumented.
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <vector>
 #include "../include/mk_krylov.h"
 
@@ -91,6 +92,75 @@ static void more_kernels() {
 }
 
 // communicators destroyed before the matrices created on them (a host language's finaliser order)
+// three unknowns per node: a grid of nodes (index patterns with a shape table), random neighbour nodes (shared column lists),
+// and short rows with a few long ones (split kernel, pieces summed by a wave)
+static void product_all_modes(int n, std::vector<int> &rp, std::vector<int> &ci, std::vector<double> &v, const char *what) {
+  SparseMatrixCSR csr = {};
+  csr.values = v.data(); csr.row_pointers = rp.data(); csr.column_indices = ci.data();
+  csr.nrows = (unsigned)n; csr.ncolumns = (unsigned)n; csr.nnz = (unsigned)ci.size();
+  mk_matrix *A = nullptr;
+  CK(mk_matrix_from_csr(&csr, &A));
+  mk_matrix_info info; CK(mk_matrix_get_info(A, &info));
+  printf("  %s: kernel %d, %lld index patterns, %lld shared column entries, lanes %d chunk %d\n", what, info.kernel,
+         (long long)info.index_patterns, (long long)info.shared_columns, info.stream_lanes, info.stream_chunk);
+  mk_vector *x, *y, *b; CK(mk_vector_create(n, &x)); CK(mk_vector_create(n, &y)); CK(mk_vector_create(n, &b));
+  CK(mk_vector_fill(x, 1.0)); CK(mk_vector_fill(b, 1.0));
+  CK(mk_spmv(A, 1.0, x, 0.0, y)); CK(mk_spmv(A, 0.5, x, 2.0, y));
+  double a, b2; CK(mk_spmv_dot(A, x, y, &a, &b2));
+  { mk_jacobi *S; CK(mk_jacobi_create(&S)); CK(mk_jacobi_set_max_iter(S, 5)); CK(mk_vector_fill(x, 0.0));
+    CK(mk_jacobi_setup(S, A, b, x)); CK(mk_jacobi_solve(S, A, b, x)); CK(mk_jacobi_destroy(S)); }
+  CK(mk_vector_destroy(x)); CK(mk_vector_destroy(y)); CK(mk_vector_destroy(b)); CK(mk_matrix_destroy(A));
+}
+
+static void fem_kernels() {
+  unsigned long long st = 12345;
+  auto rnd = [&]() { st = st * 6364136223846793005ULL + 1442695040888963407ULL; return (unsigned)(st >> 33); };
+  {  // 27 node neighbours x 3x3 blocks on a 12 x 9 x 8 grid of nodes
+    const int nx = 12, ny = 9, nz = 8, nn = nx * ny * nz;
+    std::vector<int> rp(1, 0), ci; std::vector<double> v;
+    for (int node = 0; node < nn; node++) {
+      const int ix = node % nx, iy = (node / nx) % ny, iz = node / (nx * ny);
+      for (int d = 0; d < 3; d++) {
+        for (int dz = -1; dz <= 1; dz++) for (int dy = -1; dy <= 1; dy++) for (int dx = -1; dx <= 1; dx++) {
+          if (ix + dx < 0 || ix + dx >= nx || iy + dy < 0 || iy + dy >= ny || iz + dz < 0 || iz + dz >= nz) continue;
+          const int nb = node + dx + dy * nx + dz * nx * ny;
+          for (int e = 0; e < 3; e++) { ci.push_back(3 * nb + e); v.push_back(nb == node && e == d ? 200.0 : -1.0 - 0.001 * (rnd() % 1000)); }
+        }
+        rp.push_back((int)ci.size());
+      }
+    }
+    product_all_modes(3 * nn, rp, ci, v, "node grid");
+  }
+  {  // random neighbour nodes: the three rows of a node share one column list, no two nodes a pattern
+    const int nn = 3000;
+    std::vector<int> rp(1, 0), ci; std::vector<double> v;
+    for (int node = 0; node < nn; node++) {
+      std::vector<int> nb(1, node);
+      const int k = 8 + rnd() % 20;
+      for (int t = 0; t < k; t++) { int j = node - 40 + (int)(rnd() % 81); if (j >= 0 && j < nn) nb.push_back(j); }
+      std::sort(nb.begin(), nb.end()); nb.erase(std::unique(nb.begin(), nb.end()), nb.end());
+      for (int d = 0; d < 3; d++) {
+        for (int j : nb) for (int e = 0; e < 3; e++) { ci.push_back(3 * j + e); v.push_back(j == node && e == d ? 300.0 : -1.0 - 0.001 * (rnd() % 1000)); }
+        rp.push_back((int)ci.size());
+      }
+    }
+    product_all_modes(3 * nn, rp, ci, v, "node blocks, random neighbours");
+  }
+  {  // short rows, every 3000th row 500 entries long
+    const int n = 20000;
+    std::vector<int> rp(1, 0), ci; std::vector<double> v;
+    for (int r = 0; r < n; r++) {
+      const int len = (r % 3000 == 777) ? 500 : 3 + (int)(rnd() % 6);
+      std::vector<int> c(1, r);
+      for (int t = 1; t < len; t++) c.push_back((int)(rnd() % n));
+      std::sort(c.begin(), c.end());
+      for (int j : c) { ci.push_back(j); v.push_back(j == r ? 1000.0 : -1.0); }
+      rp.push_back((int)ci.size());
+    }
+    product_all_modes(n, rp, ci, v, "short rows with long ones");
+  }
+}
+
 static void comm_first() {
   const int R = 3, nx = 16, ny = 12, nz = 18;
   const int64_t n = (int64_t)nx * ny * nz;
@@ -157,6 +227,8 @@ int main() {
   rmat();
   printf("more kernels\n");
   more_kernels();
+  printf("finite-element shapes\n");
+  fem_kernels();
   printf("row blocks\n");
   comm_first();
   world(64, 64, 64, 4, false, 0);
