@@ -758,6 +758,56 @@ def test_spmv_on_golden_matrices(name):
     _check_spmv(A, g["csr_rowptr"], g["csr_col"], g["csr_val"], n, nc, np.random.default_rng(1))
 
 
+@pytest.mark.parametrize("seed,n,p_same,p_empty", [(1, 5003, 0.6, 0.1), (2, 777, 0.9, 0.0), (3, 4096, 0.45, 0.3), (4, 64, 1.0, 0.0),
+                                                   (5, 9000, 1.0, 0.0)])   # (4): few rows, served by a pattern table instead; (5): every row the first row's list
+def test_spmv_shared_column_lists_mixtures(seed, n, p_same, p_empty):
+    """rows that repeat the list of the row before them, mixed with empty rows and fresh lists (also: every row the same
+    list, runs that cross chunk borders, an empty row between two equal lists): product, fused dots and a Jacobi sweep
+    through the compact column array against the oracle on the CSR as given"""
+    rng = np.random.default_rng(seed)
+    lists, prev = [], None
+    for r in range(n):
+        u = rng.random()
+        if prev is not None and prev.size and u < p_same:
+            cur = prev.copy()
+        elif u > 1.0 - p_empty and r > 0:
+            cur = np.zeros(0, np.int64)
+        else:
+            cur = np.unique(np.concatenate([[r], rng.integers(0, n, int(rng.integers(20, 60)))]))
+        lists.append(cur)
+        prev = cur
+    lens = np.array([l.size for l in lists])
+    rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    ci = np.concatenate(lists).astype(np.int32)
+    v = rng.normal(size=ci.size)
+    rows = np.repeat(np.arange(n), lens)
+    A = mk.Matrix.from_csr(n, n, rp, ci, v)
+    i = A.info()
+    same = np.array([r > 0 and lists[r].size > 0 and lists[r].size == lists[r - 1].size and np.array_equal(lists[r], lists[r - 1]) for r in range(n)])
+    if i.kernel == mk.SPMV_STREAM and i.index_patterns == 0 and lens[same].sum() >= 0.4 * ci.size and ci.size / n >= 12:
+        assert i.shared_columns == int(lens[same].sum())
+    _check_spmv(A, rp, ci, v, n, n, rng)
+    _check_spmv(A, rp, ci, v, n, n, rng, alpha=-1.5, beta=0.75)
+    xh = rng.normal(size=n)
+    x, y = mk.Vector(n, values=xh), mk.Vector(n)
+    yx, xx = A.spmv_dot(x, y)
+    ref = oracle.csr_spmv(rp, ci, v, xh)
+    assert np.allclose(y.get(), ref, rtol=1e-11, atol=1e-11) and np.isclose(yx, ref @ xh, rtol=1e-10, atol=1e-9)
+    # one Jacobi sweep (diagonal made dominant where a row has one)
+    vd = v.copy()
+    absum = np.bincount(rows, weights=np.abs(v), minlength=n)
+    dmask = ci == rows
+    vd[dmask] = 2.0 * absum[rows[dmask]] + 1.0
+    if np.bincount(rows[dmask], minlength=n).min() == 1:          # every row has its diagonal: no empty rows in this case
+        o = oracle.jacobi(rp, ci, vd, np.ones(n), tol=0.0, maxit=3, check_every=1)
+        D = mk.Matrix.from_csr(n, n, rp, ci, vd)
+        b, xs = mk.Vector(n, fill=1.0), mk.Vector(n, fill=0.0)
+        S = mk.Jacobi(max_iter=3, tol=0.0, check_every=1)
+        S.setup(D, b, xs)
+        S.solve(D, b, xs)
+        assert np.allclose(xs.get(), o["x"], rtol=1e-12, atol=0)
+
+
 def test_selector_long_row_among_short_ones():
     """short rows with a few long ones: the chunk capacity would fit the stream kernel, the rows of more than 32 entries per
     lane send the matrix to the split kernel; without them it stays on the stream kernel (both against the oracle)"""
