@@ -808,6 +808,38 @@ def test_spmv_shared_column_lists_mixtures(seed, n, p_same, p_empty):
         assert np.allclose(xs.get(), o["x"], rtol=1e-12, atol=0)
 
 
+@pytest.mark.parametrize("dof,nx,ny", [(2, 37, 23), (4, 20, 31)])
+def test_spmv_pattern_shapes_short_rows(dof, nx, ny):
+    """several unknowns per node of a 2-D 5-point grid, every entry its own value: the index patterns of a node's rows differ
+    by a shift only, so the stream kernel stages shapes + (shape, shift) per pattern; one lane per row, hence the
+    reference's summation order: bit-identical to the oracle, also with empty rows in between"""
+    rng = np.random.default_rng(dof)
+    nn = nx * ny
+    lists = []
+    for node in range(nn):
+        ix, iy = node % nx, node // nx
+        nb = [node + d for d, ok in ((-nx, iy > 0), (-1, ix > 0), (0, True), (1, ix < nx - 1), (nx, iy < ny - 1)) if ok]
+        cols = np.array([dof * j + e for j in nb for e in range(dof)], np.int64)
+        for d in range(dof):
+            lists.append(cols if not (node % 97 == 5 and d == 1) else np.zeros(0, np.int64))     # a few empty rows
+    n = dof * nn
+    lens = np.array([l.size for l in lists])
+    rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    ci = np.concatenate(lists).astype(np.int32)
+    v = rng.normal(size=ci.size)
+    A = mk.Matrix.from_csr(n, n, rp, ci, v)
+    i = A.info()
+    assert i.kernel == mk.SPMV_STREAM and i.stream_lanes <= 2 and dof * 9 <= i.index_patterns <= dof * 9 + 1
+    xh = rng.normal(size=n)
+    x, y = mk.Vector(n, values=xh), mk.Vector(n)
+    A.spmv(x, y)
+    if i.stream_lanes == 1:
+        assert np.array_equal(y.get(), oracle.csr_spmv(rp, ci, v, xh))
+    _check_spmv(A, rp, ci, v, n, n, rng, alpha=0.25, beta=-2.0)
+    yx, xx = A.spmv_dot(x, y)
+    assert np.isclose(yx, oracle.csr_spmv(rp, ci, v, xh) @ xh, rtol=1e-11, atol=1e-9)
+
+
 def test_selector_long_row_among_short_ones():
     """short rows with a few long ones: the chunk capacity would fit the stream kernel, the rows of more than 32 entries per
     lane send the matrix to the split kernel; without them it stays on the stream kernel (both against the oracle)"""
