@@ -63,6 +63,60 @@ def test_dist_spmv_all_to_all_rmat():
     assert (np.abs(got - ref) / np.maximum(mag, 1e-300)).max() <= 1e-12
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_dist_node_block_matrix_spmv_and_pcg(world):
+    """a finite-element-like matrix (three unknowns per node, random neighbour nodes, symmetric, dominant diagonal) cut into
+    nnz-balanced row blocks: the diag blocks take the stream kernel with shared column lists, the cuts fall inside nodes;
+    product and Jacobi-preconditioned CG against the global oracle"""
+    rng = np.random.default_rng(40 + world)
+    nodes = 1500
+    pairs = set()
+    for i in range(nodes):
+        pairs.add((i, i))
+        for j in rng.integers(max(0, i - 60), min(nodes, i + 61), int(rng.integers(5, 14))):
+            pairs.add((i, int(j))); pairs.add((int(j), i))
+    pi, pj = np.array(sorted(pairs)).T
+    # node pair -> 3x3 block, symmetric values
+    w = {}
+    for a, b in zip(pi, pj):
+        if (b, a) in w:
+            w[(a, b)] = w[(b, a)].T
+        else:
+            blk = -rng.uniform(0.1, 1.0, (3, 3))
+            w[(a, b)] = (blk + blk.T) / 2 if a == b else blk
+    rows, cols, vals = [], [], []
+    for a, b in zip(pi, pj):
+        for d in range(3):
+            for e in range(3):
+                rows.append(3 * a + d); cols.append(3 * b + e); vals.append(w[(a, b)][d, e])
+    rows, cols, vals = np.array(rows), np.array(cols), np.array(vals)
+    order = np.lexsort((cols, rows))
+    rows, cols, vals = rows[order], cols[order].astype(np.int32), vals[order]
+    n = 3 * nodes
+    absum = np.bincount(rows, weights=np.abs(vals), minlength=n)
+    vals[rows == cols] = 1.2 * absum[rows[rows == cols]]
+    rp = np.concatenate([[0], np.cumsum(np.bincount(rows, minlength=n))]).astype(np.int32)
+    rs = mk.partition_rows(rp, world)
+    comms = mkd.Comm.local_world(world)
+    As = _blocks(rp, cols, vals, n, rs, comms)
+    xh = rng.normal(size=n)
+    xs = [A.vector(values=xh[rs[k]:rs[k + 1]]) for k, A in enumerate(As)]
+    ys = [A.vector() for A in As]
+    mkd.dist_spmv(As, xs, ys)
+    got = np.concatenate([y.get() for y in ys])
+    ref = oracle.csr_spmv(rp, cols, vals, xh)
+    mag = oracle.csr_spmv(rp, cols, np.abs(vals), np.abs(xh))
+    assert (np.abs(got - ref) / np.maximum(mag, 1e-300)).max() <= 1e-12
+    o = oracle.pcg(rp, cols, vals, np.ones(n), tol=1e-9, precond=1, maxit=500, want_norms=True)
+    bs = [A.vector(fill=1.0) for A in As]
+    x0 = [A.vector(fill=0.0) for A in As]
+    Ss = [mk.PCG(max_iter=500, tol=1e-9, precond=1, logging=1, check_every=7) for _ in As]
+    res = mkd.dist_pcg_solve(Ss, As, bs, x0)
+    assert res[0]["converged"] == 1 and abs(res[0]["iterations"] - o["iterations"]) <= 2
+    xg = np.concatenate([x.get() for x in x0])
+    assert np.linalg.norm(xg - o["x"]) <= 1e-7 * np.linalg.norm(o["x"])
+
+
 @pytest.mark.parametrize("world,precond", [(1, 0), (2, 1), (4, 0), (8, 1)])
 def test_dist_pcg_matches_oracle(world, precond):
     rp, ci, v = oracle.stencil_csr(7, 16, 16, 24)
