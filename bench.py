@@ -14,7 +14,8 @@ At N = 1 the line also carries
     12 nnz + 20 n + 4, its duration taken by HIP events inside the solve loop (mk_pcg_set_kernel_timing);
   * `roofline_value_loop`: the kernels of the loop `value` times (constant coefficients: the two sweeps of the fused
     step, which read a 2-byte pattern id per row instead of the CSR arrays), priced on THEIR bytes;
-  * `secondary`: BASELINE.json configs[1] (256^3 Jacobi-PCG) and configs[2] (R-MAT scale 24: COO->CSR + SpMV);
+  * `secondary`: BASELINE.json configs[1] (256^3 Jacobi-PCG) and configs[2] (R-MAT scale 24: COO->CSR + SpMV), and the product on two
+    finite-element-like CSR matrices built on the host (tools/fem_probe.py: the shape of the reference's SuiteSparse inputs);
   * `cpu_baseline`: the oracle's OpenMP CG on the full 512^3 operator on the host cores.
 
 `python bench.py --cpu-configs c1,c2,c3` is a separate mode (one JSON line per configuration, not the contract line): the
@@ -483,6 +484,33 @@ def main():
             del A3, x3, y3, coo
         except mk.MkError as e:      # never lose the headline to a secondary measurement
             sec["rmat_s24"] = {"error": str(e)}
+        # finite-element-like CSR matrices (the shape of the reference's SuiteSparse inputs, scripts/bench_all_gpu:2), built on the
+        # host by tools/fem_probe.py's generators: three unknowns per node of a 64^3 hexahedral mesh (81 entries per row, index
+        # patterns) and three unknowns per node with random neighbour nodes (no patterns; rows of a node share their column list)
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import fem_probe
+            import numpy as np
+            for fname, (fn, rp, ci) in (("fem_hex3_64", fem_probe.hex3(64)), ("fem_rand3_500k", fem_probe.rand3(500000, 26, 300))):
+                vals = np.random.default_rng(0).normal(size=ci.size)
+                A4 = mk.Matrix.from_csr(fn, fn, rp, ci, vals)
+                i4 = A4.info()
+                x4, y4 = mk.Vector(fn, fill=1.0), mk.Vector(fn)
+                for _ in range(3):
+                    A4.spmv(x4, y4)
+                mk.timer_start()
+                for _ in range(20):
+                    A4.spmv(x4, y4)
+                ms4 = mk.timer_stop() / 20
+                b4 = 12 * ci.size + 20 * fn + 4
+                sec[fname] = {"rows": fn, "nnz": int(ci.size), "mean_row_len": round(ci.size / fn, 1), "max_row_len": i4.max_row_len,
+                              "spmv_ms": round(ms4, 4), "spmv_frac": round(b4 / (ms4 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                              "spmv_bytes_model": "SURVEY 8(d): 12 nnz + 20 n + 4", "spmv_kernel": KERNEL_NAMES.get(i4.kernel),
+                              "index_patterns": i4.index_patterns, "shared_column_entries": i4.shared_columns,
+                              "stream_lanes": i4.stream_lanes, "stream_chunk": i4.stream_chunk}
+                del A4, x4, y4, vals
+        except Exception as e:      # never lose the headline to a secondary measurement
+            sec["fem_like"] = {"error": repr(e)}
         out["secondary"] = sec
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(kind, nx, ny, nz, precond, args.cpu_iters)

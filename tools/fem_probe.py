@@ -124,16 +124,21 @@ def nine(N):
     return N * N, rp, cols
 
 
-args = sys.argv[1:] or ["hex3", "64"]
-mk.init(0)
-while args:
-    if args[0] == "nine":
-        run(f"nine {args[1]}", *nine(int(args[1]))); args = args[2:]
-    elif args[0] == "skew":
-        run(f"skew {args[1]} {args[2]} {args[3]} {args[4]}", *skew(*(int(a) for a in args[1:5]))); args = args[5:]
-    elif args[0] == "rand3":
-        run(f"rand3 {args[1]} {args[2]} {args[3]}", *rand3(int(args[1]), int(args[2]), int(args[3]))); args = args[4:]
-    elif args[0] == "hex3":
-        run(f"hex3 {args[1]}", *hex3(int(args[1]))); args = args[2:]
-    else:
-        run(f"rand {args[1]} {args[2]} {args[3]}", *rand(int(args[1]), int(args[2]), int(args[3]))); args = args[4:]
+def main():
+    args = sys.argv[1:] or ["hex3", "64"]
+    mk.init(0)
+    while args:
+        if args[0] == "nine":
+            run(f"nine {args[1]}", *nine(int(args[1]))); args = args[2:]
+        elif args[0] == "skew":
+            run(f"skew {args[1]} {args[2]} {args[3]} {args[4]}", *skew(*(int(a) for a in args[1:5]))); args = args[5:]
+        elif args[0] == "rand3":
+            run(f"rand3 {args[1]} {args[2]} {args[3]}", *rand3(int(args[1]), int(args[2]), int(args[3]))); args = args[4:]
+        elif args[0] == "hex3":
+            run(f"hex3 {args[1]}", *hex3(int(args[1]))); args = args[2:]
+        else:
+            run(f"rand {args[1]} {args[2]} {args[3]}", *rand(int(args[1]), int(args[2]), int(args[3]))); args = args[4:]
+
+
+if __name__ == "__main__":
+    main()
