@@ -1783,11 +1783,14 @@ __global__ void split_chunk_rows_kernel(int64_t nrows, int64_t nnz, const int *_
   }
 }
 
+#ifndef MK_SPLIT_GROUP
+#define MK_SPLIT_GROUP 2
+#endif
 #ifndef MK_LONG_PIECE
 #define MK_LONG_PIECE 64
 #endif
 template <int MODE, bool NT>   // NT: the matrix does not fit the Infinity Cache, it streams past nontemporally and the caches keep x
-__global__ __launch_bounds__(kThreads) void spmv_split_kernel(
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void spmv_split_kernel(
     int64_t nrows, int64_t nnz, const int *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ val,
     const int *__restrict__ chunk_row, int nchunks, const double *__restrict__ x, double *__restrict__ y, double alpha,
     double beta, double *__restrict__ carry, double *__restrict__ slab, const int *__restrict__ done,
@@ -1806,20 +1809,45 @@ __global__ __launch_bounds__(kThreads) void spmv_split_kernel(
     const int64_t e0 = (int64_t)c * kSplitChunk;
     const int64_t e1 = min(e0 + kSplitChunk, nnz);
     if (tid == 0) long_n = 0;   // read again only behind the barrier that follows pass 1
-    // pass 1
+    // pass 1: all matrix loads of the thread first, then all its gathers, then the products -- written with clamped addresses
+    // instead of per-piece branches, which made the compiler wait for each piece's loads and gathers in turn (8 round trips
+    // per chunk).  Pairs beyond the end of the last chunk re-read its last pair and store zeros.
+    {
+      typedef int i2_t __attribute__((ext_vector_type(2)));
+      constexpr int NP = kSplitChunk / (2 * kThreads);
+      const int64_t klast = max(e0, (e1 - 1) & ~(int64_t)1);   // last pair that starts inside the chunk
+      constexpr int GP = MK_SPLIT_GROUP;                          // pieces whose loads and gathers are in flight together
+      if (e0 >= e1) {   // a matrix without entries: nothing to read, the rows are written as zeros in pass 2
 #pragma unroll
-    for (int i = 0; i < kSplitChunk / (2 * kThreads); i++) {
-      const int64_t k = e0 + (int64_t)(tid + i * kThreads) * 2;
-      double p0 = 0.0, p1 = 0.0;
-      if (k < e1) {
-        // the matrix streams past once; x is what the caches are for
-        typedef int i2_t __attribute__((ext_vector_type(2)));
-        const d2_t v = NT ? __builtin_nontemporal_load(reinterpret_cast<const d2_t *>(val + k)) : *reinterpret_cast<const d2_t *>(val + k);
-        const i2_t cc = NT ? __builtin_nontemporal_load(reinterpret_cast<const i2_t *>(col + k)) : *reinterpret_cast<const i2_t *>(col + k);
-        p0 = v.x * xg[cc.x];
-        if (k + 1 < e1) p1 = v.y * xg[cc.y];
+        for (int i = 0; i < NP; i++) *reinterpret_cast<double2 *>(prod + (tid + i * kThreads) * 2) = make_double2(0.0, 0.0);
+      } else {
+#pragma unroll
+        for (int i0 = 0; i0 < NP; i0 += GP) {
+          d2_t vv[GP];
+          i2_t cc[GP];
+          double xa[GP], xb[GP];
+#pragma unroll
+          for (int i = 0; i < GP; i++) {
+            const int64_t k = min(e0 + (int64_t)(tid + (i0 + i) * kThreads) * 2, klast);
+            vv[i] = NT ? __builtin_nontemporal_load(reinterpret_cast<const d2_t *>(val + k)) : *reinterpret_cast<const d2_t *>(val + k);
+            cc[i] = NT ? __builtin_nontemporal_load(reinterpret_cast<const i2_t *>(col + k)) : *reinterpret_cast<const i2_t *>(col + k);
+          }
+#pragma unroll
+          for (int i = 0; i < GP; i++) {
+            const int64_t k = min(e0 + (int64_t)(tid + (i0 + i) * kThreads) * 2, klast);
+            const int cy = (k + 1 < e1) ? cc[i].y : cc[i].x;       // the slot behind an odd end holds no column
+            xa[i] = xg[cc[i].x];
+            xb[i] = xg[cy];
+          }
+#pragma unroll
+          for (int i = 0; i < GP; i++) {
+            const int64_t k = e0 + (int64_t)(tid + (i0 + i) * kThreads) * 2;
+            const double p0 = (k < e1) ? vv[i].x * xa[i] : 0.0;
+            const double p1 = (k + 1 < e1) ? vv[i].y * xb[i] : 0.0;
+            *reinterpret_cast<double2 *>(prod + (k - e0)) = make_double2(p0, p1);
+          }
+        }
       }
-      *reinterpret_cast<double2 *>(prod + (k - e0)) = make_double2(p0, p1);
     }
     __syncthreads();
     // pass 2
