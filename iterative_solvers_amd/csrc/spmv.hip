@@ -1987,7 +1987,19 @@ __global__ __launch_bounds__(kThreads) void split_fixup_kernel(
 static __global__ void gather_x_kernel(int64_t n, const int *__restrict__ order, const double *__restrict__ x, double *__restrict__ xg,
                                        const int *__restrict__ done) {
   if (done != nullptr && *done != 0) return;
-  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) xg[j] = x[order[j]];
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; j + 3 * stride < n; j += 4 * stride) {   // four index loads, then four gathers in flight per lane
+    int o[4];
+    double v[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) o[k] = order[j + k * stride];
+#pragma unroll
+    for (int k = 0; k < 4; k++) v[k] = x[o[k]];
+#pragma unroll
+    for (int k = 0; k < 4; k++) xg[j + k * stride] = v[k];
+  }
+  for (; j < n; j += stride) xg[j] = x[order[j]];
 }
 
 static int prepare_split(mk_matrix *A) {
