@@ -1790,7 +1790,7 @@ __global__ void split_chunk_rows_kernel(int64_t nrows, int64_t nnz, const int *_
 #define MK_LONG_PIECE 64
 #endif
 template <int MODE, bool NT>   // NT: the matrix does not fit the Infinity Cache, it streams past nontemporally and the caches keep x
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void spmv_split_kernel(
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(MODE == 1 ? 6 : 8, 8))) void spmv_split_kernel(
     int64_t nrows, int64_t nnz, const int *__restrict__ rowptr, const int *__restrict__ col, const double *__restrict__ val,
     const int *__restrict__ chunk_row, int nchunks, const double *__restrict__ x, double *__restrict__ y, double alpha,
     double beta, double *__restrict__ carry, double *__restrict__ slab, const int *__restrict__ done,
