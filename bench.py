@@ -38,6 +38,11 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# SURVEY.md 8(d) timing rules for the CPU leg: OMP_PROC_BIND=spread (mirrors scripts/job_amd:103), set before any OpenMP
+# runtime is loaded (torch brings one, the oracle's libgomp another); a caller's own setting wins
+os.environ.setdefault("OMP_PROC_BIND", "spread")
+TIMED_SOLVES = 5    # median of 5 timed solves, x0 reset before each
+
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (a float4 copy measures 6.29)
 
 WORKLOADS = {
@@ -235,19 +240,61 @@ def _free_port():
 def spawn_ranks(ngpus, argv):
     """`python bench.py --gpus N` without a launcher: this parent (which never touches the GPU) starts N children of the
     same script with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, relays rank 0's line, and returns the worst exit code"""
+    import tempfile
     port = _free_port()
-    procs = []
-    for r in range(ngpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(ngpus), LOCAL_WORLD_SIZE=str(ngpus),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out, _ = procs[0].communicate()
-    rc = procs[0].returncode
-    for p in procs[1:]:
-        rc = max(rc, abs(p.wait()))
-    sys.stdout.write(out)
-    sys.stdout.flush()
+    procs, logs = [], []
+    with tempfile.TemporaryDirectory(prefix="mk_bench_") as tmp:
+        for r in range(ngpus):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(ngpus), LOCAL_WORLD_SIZE=str(ngpus),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            # stdout / stderr of every rank go to files: no pipe can fill up while this parent polls
+            fo, fe = open(os.path.join(tmp, f"out{r}"), "w+"), open(os.path.join(tmp, f"err{r}"), "w+")
+            logs.append((fo, fe))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=fo, stderr=fe))
+        # Poll ALL children: a rank that dies (bad device, out of memory, RCCL init failure) leaves the others blocked in the
+        # rendezvous or in a collective for ever.  On the first non-zero exit the rest are terminated (they are fresh
+        # children of this parent, nothing is re-executed) and the run fails with that rank's stderr tail.
+        failed, rc = None, 0
+        while failed is None and any(p.poll() is None for p in procs):
+            for r, p in enumerate(procs):
+                if p.poll() not in (None, 0):
+                    failed = r
+                    break
+            else:
+                time.sleep(0.05)
+        if failed is None:
+            for r, p in enumerate(procs):
+                if p.returncode != 0 and failed is None:
+                    failed = r
+        if failed is not None:
+            rc = abs(procs[failed].returncode) or 1
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            deadline = time.time() + 10.0
+            for p in procs:
+                try:
+                    p.wait(timeout=max(0.1, deadline - time.time()))
+                except subprocess.TimeoutExpired:
+                    p.kill()
+                    p.wait()
+            fe = logs[failed][1]
+            fe.flush(); fe.seek(0)
+            tail = fe.read()[-4000:]
+            sys.stderr.write(f"bench.py: rank {failed} of {ngpus} exited with code {procs[failed].returncode}; the other ranks were "
+                             f"terminated.  Its stderr tail:\n{tail}\n")
+        else:
+            fo = logs[0][0]
+            fo.flush(); fo.seek(0)
+            sys.stdout.write(fo.read())
+            sys.stdout.flush()
+            for r, (_, fe) in enumerate(logs):      # warnings of the ranks stay visible
+                fe.flush(); fe.seek(0)
+                err = fe.read()
+                if err.strip():
+                    sys.stderr.write(err if r == 0 else "".join(f"[rank {r}] {ln}\n" for ln in err.splitlines()[-20:]))
+        for fo, fe in logs:
+            fo.close(); fe.close()
     return rc
 
 
@@ -257,6 +304,10 @@ def dry_run_rank(args, rank, world):
     import torch.distributed as dist
     from iterative_solvers_amd import distributed as mkd
     dist.init_process_group("gloo")
+    if os.environ.get("MK_BENCH_DRY_FAIL_RANK") == str(rank):   # test: one rank dies after the rendezvous, the others wait in the barrier
+        sys.stderr.write(f"dry run: rank {rank} fails on purpose\n")
+        sys.stderr.flush()
+        os._exit(7)
     ident = mkd.broadcast_bytes(bytes(range(256)) if rank == 0 else None, 256, 0)
     t = torch.tensor([float(rank)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -316,6 +367,8 @@ def main():
     if os.path.exists(tpath):
         traffic_db = json.load(open(tpath))
 
+    solve_times = {}
+
     def measure(name, steps, warmup, timing=True):
         """CG on workload `name`: a warm-up solve, the timed solve (wall clock around mk_pcg_solve, stream drained on
         both sides), then one more solve with HIP events around every kernel of iterations 2..33"""
@@ -341,7 +394,10 @@ def main():
             return dt, res, (S.kernel_timing() if timed_kernels else None)
 
         run(max(warmup, 1))
-        dt, res, _ = run(steps)
+        runs = [run(steps) for _ in range(TIMED_SOLVES)]          # EXACTLY `steps` iterations each; the median solve is reported
+        runs.sort(key=lambda t: t[0])
+        dt, res, _ = runs[len(runs) // 2]
+        solve_times[name] = [round(t[0] * 1e3 / steps, 4) for t in runs]
         kt = run(34, True)[2] if timing else None
         return A, dt, res, kt
 
@@ -395,6 +451,8 @@ def main():
                    "spmv_kernel": kname, "index_patterns": info.index_patterns, "value_patterns": info.value_patterns,
                    "parallelism": "1 GPU"},
         "final_rel_res_norm": res["rel_res_norm"],
+        "timing": {"rule": f"median of {TIMED_SOLVES} timed solves of exactly `steps` iterations each after one warm-up solve of `warmup` "
+                           "iterations, x0 reset before every solve (SURVEY.md 8(d))", "ms_per_step_of_each_solve": solve_times[name]},
         # the loop `value` times, kernel by kernel, on the bytes those kernels move (NOT the CSR model: on constant-
         # coefficient grids they read a 2-byte pattern id per row and none of the CSR arrays)
         "roofline_value_loop": {"note": "kernels of the timed CG loop, durations by HIP events inside mk_pcg_solve "
@@ -436,7 +494,8 @@ def main():
             "index_patterns": vinfo.index_patterns, "value_patterns": vinfo.value_patterns,
             "cg": {"value": round(args.steps / vdt, 2), "unit": "CG iterations/s", "ms_per_step": round(vms, 4),
                    "iteration_bytes": viter, "iteration_GBps": round(viter / (vms * 1e-3) / 1e9, 1),
-                   "iteration_frac": round(viter / (vms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "kernels": vblocks},
+                   "iteration_frac": round(viter / (vms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                   "ms_per_step_of_each_solve": solve_times[vname], "kernels": vblocks},
         }
     else:
         k1 = blocks[0]

@@ -101,32 +101,27 @@ static void print_system_files(int rank, long long row_lo, const SparseMatrixCSR
   }
 }
 
-/* Rank 0 draws the communicator id and leaves it in `path` (written under another name first, then renamed, so
- * that nobody reads half a file); the others wait for it.  With MPI at hand this is one MPI_Bcast of 256 bytes
- * (INTEGRATION.md); the driver itself needs no MPI. */
+/* Rank 0 draws the communicator id and leaves it in `path`; the others wait for THIS launch's file (idfile.c: leftovers of
+ * a run that died are recognised by their launch nonce or their age).  With MPI at hand this is one MPI_Bcast of 256
+ * bytes; the driver itself needs no MPI.  Rank 0 removes the file on every exit path it controls. */
+static const char *g_id_file_to_remove = NULL;
+static void remove_id_file(void) {
+  if (g_id_file_to_remove) remove(g_id_file_to_remove);
+}
 static int exchange_comm_id(const char *path, int rank, unsigned char *id256) {
-  char tmp[4096];
   if (rank == 0) {
+    mk_idfile_clear(path);                 /* before anything slow: a leftover must not be there when the others look */
+    g_id_file_to_remove = path;
+    atexit(remove_id_file);                /* error returns and exit() alike */
     if (mk_comm_get_unique_id(id256) != 0) { fprintf(stderr, "mk_comm_get_unique_id: %s\n", mk_last_error_string()); return 1; }
-    snprintf(tmp, sizeof tmp, "%s.tmp", path);
-    FILE *f = fopen(tmp, "wb");
-    if (!f || fwrite(id256, 1, 256, f) != 256 || fclose(f) != 0 || rename(tmp, path) != 0) {
-      fprintf(stderr, "cannot write the communicator id to %s\n", path);
-      return 1;
-    }
+    if (mk_idfile_publish(path, id256) != 0) { fprintf(stderr, "cannot write the communicator id to %s\n", path); return 1; }
     return 0;
   }
-  for (int tries = 0; tries < 6000; tries++) {   /* up to 10 minutes: rank 0 may still be parsing */
-    FILE *f = fopen(path, "rb");
-    if (f) {
-      const size_t got = fread(id256, 1, 256, f);
-      fclose(f);
-      if (got == 256) return 0;
-    }
-    usleep(100000);
-  }
-  fprintf(stderr, "rank %d: no communicator id appeared in %s\n", rank, path);
-  return 1;
+  const char *age = getenv("MK_ID_FILE_MAX_AGE");
+  const int rc = mk_idfile_wait(path, id256, 600.0 /* rank 0 may still be starting */, age ? atof(age) : 120.0);
+  if (rc == 2) fprintf(stderr, "rank %d: %s holds the id of another launch (stale file?) and no new one appeared\n", rank, path);
+  else if (rc != 0) fprintf(stderr, "rank %d: no communicator id appeared in %s\n", rank, path);
+  return rc != 0;
 }
 
 /* -np N: this process is one rank of N (solvers.c with num_procs > 1).  Every rank reads the file, keeps the rows
@@ -255,7 +250,7 @@ static int run_distributed(const char *mtx, const char *bfile, const char *xfile
   mk_vector_destroy(x);
   mk_dist_matrix_destroy(A);
   mk_comm_destroy(comm);
-  if (rank == 0 && id_file) remove(id_file);
+  if (rank == 0 && id_file) { remove(id_file); g_id_file_to_remove = NULL; }
   mk_finalize();
   return 0;
 }

@@ -227,7 +227,10 @@ int fast_load_from_mtx_file(const char *path, SparseMatrixCOO *coo) {
   if (nthreads > 64) nthreads = 64;
   int rc = -1;
   if (nthreads > 1 && entries >= min_entries) rc = parse_parallel(text, got, entries, sym, pat, nthreads, coo);
+  const int took_parallel = (rc != -1);
   if (rc == -1) rc = parse_serial(path, text, entries, sym, pat, coo);
+  if (getenv("MK_PARSE_TRACE"))   /* tests: which parser read the file */
+    fprintf(stderr, "Matrix Market parser: %s (%u entries, %d threads)\n", took_parallel ? "parallel" : "serial", entries, took_parallel ? nthreads : 1);
   free(text);
   if (rc != 0) free_coo(coo);
   return rc;

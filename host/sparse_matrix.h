@@ -35,6 +35,11 @@ int read_csr_cache_for(const char *path, SparseMatrixCSR *m, const char *src_mtx
 int coo_row_pointers64(const SparseMatrixCOO *coo, long long *rowptr);
 int slice_coo_rows(const SparseMatrixCOO *coo, long long row_lo, long long row_hi, SparseMatrixCOO *out);
 int write_stencil_mtx(const char *path, int kind, int nx, int ny, int nz);   /* synthetic test input */
+/* -id_file: the communicator id from rank 0 to the others through a shared directory (idfile.c; stands in for MPI_Bcast) */
+void mk_idfile_nonce(char *nonce64);
+void mk_idfile_clear(const char *path);
+int mk_idfile_publish(const char *path, const unsigned char *id256);
+int mk_idfile_wait(const char *path, unsigned char *id256, double timeout_s, double max_age_s);
 #ifdef __cplusplus
 }
 #endif

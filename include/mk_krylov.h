@@ -85,6 +85,9 @@ int mk_synchronize(void);
  * in the list.  mk_memory_trim() gives the idle blocks back to the driver (a long-running host does this after set-up). */
 int mk_memory_info(long long *in_use_bytes, long long *idle_bytes);
 int mk_memory_trim(void);
+/* how often the library has asked its allocator for a block / given one back since mk_init (whether the request went to
+ * hipMalloc / hipFree or to the free list): lets a caller check that a code path allocates nothing */
+int mk_memory_calls(long long *alloc_calls, long long *free_calls);
 /* HIP-event timers on that stream: start, stop, then elapsed (milliseconds, synchronises) */
 int mk_timer_start(void);
 int mk_timer_stop(float *elapsed_ms);

@@ -44,7 +44,7 @@ PRECOND_NONE, PRECOND_JACOBI = 0, 1
 # every symbol include/mk_krylov.h declares (tests check the library exports all of them)
 EXPORTS = [
     "mk_init", "mk_finalize", "mk_last_error_string", "mk_get_stream", "mk_get_device_pci_bus_id", "mk_synchronize",
-    "mk_memory_info", "mk_memory_trim",
+    "mk_memory_info", "mk_memory_trim", "mk_memory_calls",
     "mk_timer_start", "mk_timer_stop",
     "mk_sort_coo_row", "mk_coo_to_csr",
     "mk_matrix_from_coo", "mk_matrix_from_csr", "mk_matrix_from_device_coo", "mk_matrix_destroy",
@@ -195,6 +195,13 @@ def memory_info():
     """(bytes inside live objects, bytes idle in the allocator's free list)"""
     a, b = C.c_longlong(), C.c_longlong()
     _ck(load().mk_memory_info(C.byref(a), C.byref(b)))
+    return a.value, b.value
+
+
+def memory_calls():
+    """(requests to, releases into) the library's allocator since mk_init"""
+    a, b = C.c_longlong(), C.c_longlong()
+    _ck(load().mk_memory_calls(C.byref(a), C.byref(b)))
     return a.value, b.value
 
 

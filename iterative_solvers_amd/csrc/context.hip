@@ -32,6 +32,7 @@ struct AllocCache {
   std::unordered_map<void *, size_t> live;        // every block handed out -> its size
   std::multimap<size_t, void *> idle;             // blocks waiting for reuse, by size
   size_t idle_bytes = 0, cap = 0;
+  long long alloc_calls = 0, free_calls = 0;
   bool enabled = false;
 };
 AllocCache g_cache;
@@ -50,6 +51,7 @@ void *cached_alloc(size_t bytes) {
   void *p = nullptr;
   {
     std::lock_guard<std::mutex> lk(g_cache.mu);
+    g_cache.alloc_calls++;
     if (g_cache.enabled && bytes >= kCacheMinBlock) {
       auto it = g_cache.idle.lower_bound(bytes);
       if (it != g_cache.idle.end() && it->first <= bytes + bytes / 8) {
@@ -76,10 +78,36 @@ void *cached_alloc(size_t bytes) {
   return p;
 }
 
+// Streams other than ctx().stream that library work runs on (RCCL communication streams, the local world's side stream).
+// A block that goes back to the free list may be handed to a new user at once, whose work is ordered behind the old
+// user's only on ctx().stream; so before a block is kept for reuse every side stream must have drained.  The solvers
+// join their side streams back into ctx().stream by events before they return, so the query below normally finds
+// them idle (a few microseconds per free, nothing on the single-GPU path: no side stream exists there).
+static std::vector<hipStream_t> g_side_streams;
+void register_side_stream(hipStream_t s) {
+  std::lock_guard<std::mutex> lk(g_cache.mu);
+  g_side_streams.push_back(s);
+}
+void unregister_side_stream(hipStream_t s) {
+  std::lock_guard<std::mutex> lk(g_cache.mu);
+  for (size_t i = 0; i < g_side_streams.size(); i++)
+    if (g_side_streams[i] == s) { g_side_streams.erase(g_side_streams.begin() + i); break; }
+}
+
 void cached_free(void *p) {
   size_t bytes = 0;
   {
+    std::vector<hipStream_t> side;
+    {
+      std::lock_guard<std::mutex> lk(g_cache.mu);
+      if (g_cache.enabled) side = g_side_streams;
+    }
+    for (hipStream_t s : side)
+      if (hipStreamQuery(s) != hipSuccess) { (void)hipGetLastError(); (void)hipStreamSynchronize(s); }
+  }
+  {
     std::lock_guard<std::mutex> lk(g_cache.mu);
+    g_cache.free_calls++;
     auto it = g_cache.live.find(p);
     if (it != g_cache.live.end()) {
       bytes = it->second;
@@ -92,6 +120,11 @@ void cached_free(void *p) {
     }
   }
   (void)hipFree(p);
+}
+
+int &dry_launch() {
+  static int flag = 0;
+  return flag;
 }
 
 Context &ctx() {
@@ -191,6 +224,14 @@ int mk_memory_info(long long *in_use_bytes, long long *idle_bytes) {
   for (auto &b : g_cache.live) live += (long long)b.second;
   if (in_use_bytes) *in_use_bytes = live;
   if (idle_bytes) *idle_bytes = (long long)g_cache.idle_bytes;
+  return MK_OK;
+}
+
+int mk_memory_calls(long long *alloc_calls, long long *free_calls) {
+  MK_REQUIRE_INIT();
+  std::lock_guard<std::mutex> lk(g_cache.mu);
+  if (alloc_calls) *alloc_calls = g_cache.alloc_calls;
+  if (free_calls) *free_calls = g_cache.free_calls;
   return MK_OK;
 }
 

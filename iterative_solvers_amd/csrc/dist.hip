@@ -623,6 +623,7 @@ int mk_comm_create(const void *id256, int nranks, int rank, mk_comm **comm) {
   MK_NCCL(g_rccl.CommInitRank(&cm->coll, nranks, a, rank));
   MK_NCCL(g_rccl.CommInitRank(&cm->p2p, nranks, b, rank));
   MK_HIP(hipStreamCreateWithFlags(&cm->comm_stream, hipStreamNonBlocking));
+  register_side_stream(cm->comm_stream);
   MK_HIP(hipEventCreateWithFlags(&cm->ev_ready, hipEventDisableTiming));
   MK_HIP(hipEventCreateWithFlags(&cm->ev_halo, hipEventDisableTiming));
   *comm = cm;
@@ -637,6 +638,7 @@ int mk_comm_create_local(int nranks, mk_comm **comms) {
   W->mats.assign(nranks, nullptr);
   MK_TRY(dev_alloc(&W->d_ptrs, (size_t)nranks));
   MK_HIP(hipStreamCreateWithFlags(&W->side, hipStreamNonBlocking));
+  register_side_stream(W->side);
   MK_HIP(hipEventCreateWithFlags(&W->ev_ready, hipEventDisableTiming));
   MK_HIP(hipEventCreateWithFlags(&W->ev_done, hipEventDisableTiming));
   for (int r = 0; r < nranks; r++) {
@@ -718,7 +720,7 @@ static void comm_release(mk_comm *cm) {
       dev_free(W->d_ptrs);
       if (W->ev_ready) (void)hipEventDestroy(W->ev_ready);
       if (W->ev_done) (void)hipEventDestroy(W->ev_done);
-      if (W->side) (void)hipStreamDestroy(W->side);
+      if (W->side) { unregister_side_stream(W->side); (void)hipStreamDestroy(W->side); }
       delete W;
     }
   } else {
@@ -726,7 +728,7 @@ static void comm_release(mk_comm *cm) {
     if (cm->p2p) (void)g_rccl.CommDestroy(cm->p2p);
     if (cm->ev_ready) (void)hipEventDestroy(cm->ev_ready);
     if (cm->ev_halo) (void)hipEventDestroy(cm->ev_halo);
-    if (cm->comm_stream) (void)hipStreamDestroy(cm->comm_stream);
+    if (cm->comm_stream) { unregister_side_stream(cm->comm_stream); (void)hipStreamDestroy(cm->comm_stream); }
   }
   delete cm;
 }
@@ -1051,7 +1053,8 @@ int mk_dist_pcg_solve(int R, mk_pcg **solvers, mk_dist_matrix **A, mk_vector **b
     }
     if (solvers[r]->print_level > 1 && solvers[r]->norms && !zero_rhs && hst[0].iter <= S0->max_iter) {
       std::vector<double> h((size_t)hst[0].iter + 1);
-      if (hipMemcpy(h.data(), solvers[r]->norms, sizeof(double) * h.size(), hipMemcpyDeviceToHost) == hipSuccess)
+      if (hipMemcpyAsync(h.data(), solvers[r]->norms, sizeof(double) * h.size(), hipMemcpyDeviceToHost, c.stream) == hipSuccess &&
+          hipStreamSynchronize(c.stream) == hipSuccess)
         print_pcg_table(two_norm, h.data(), hst[0].iter, sqrt(hst[0].bi_prod));
     }
   }
@@ -1083,7 +1086,7 @@ int mk_dist_jacobi_solve(int R, mk_jacobi **solvers, mk_dist_matrix **A, mk_vect
   struct JW { double *xalt = nullptr, *extra = nullptr, *slab = nullptr, *buf = nullptr; JacobiState *state = nullptr; };
   std::vector<JW> W(R);
   std::vector<double *> cur(R), nxt(R), bufs(R);
-  std::vector<int> blocks(R), vb(R), split(R, 0), pb(R, 0), pe(R, 0), nplanes(R, 0);
+  std::vector<int> blocks(R), vb(R), split(R, 0), pb(R, 0), pe(R, 0), nplanes(R, 0), imax(R, kSlabStride);
   // split sweep (see the loop): default over RCCL, where the exchange has a latency worth hiding; in a local world (one GPU,
   // nothing to hide, two more launches per rank) only on request.  MK_JACOBI_SPLIT=0 / 1 forces it off / on.
   static const int env_split = getenv("MK_JACOBI_SPLIT") ? atoi(getenv("MK_JACOBI_SPLIT")) : -1;
@@ -1117,6 +1120,16 @@ int mk_dist_jacobi_solve(int R, mk_jacobi **solvers, mk_dist_matrix **A, mk_vect
       pe[r] = (int)(D->gap1 / P);               // one past the last such plane
       if (D->gap1 >= (int)D->n_local) pe[r] = K;
       split[r] = pe[r] - pb[r] >= 8 && (pb[r] > 0 || pe[r] < K);
+      if (split[r]) {
+        // The partials of the interior launch and of the (at most two) boundary launches share one slab of kSlabStride
+        // slots: decided HERE, never in the loop.  The boundary launches take what their planes need (one segment each),
+        // the interior launch gets the rest (fewer segments if need be); a grid that does not fit keeps the one-launch sweep.
+        const int b0 = pb[r] > 0 ? jacobi_sweep_blocks(&D->diag, 0, pb[r], kSlabStride) : 0;
+        const int b1 = pe[r] < K ? jacobi_sweep_blocks(&D->diag, pe[r], K, kSlabStride) : 0;
+        const bool edges_ok = (pb[r] == 0 || b0 > 0) && (pe[r] >= K || b1 > 0);
+        imax[r] = kSlabStride - b0 - b1;
+        if (!edges_ok || imax[r] < 8 || jacobi_sweep_blocks(&D->diag, pb[r], pe[r], imax[r]) <= 0) split[r] = 0;
+      }
     }
   }
   JacobiState *hst = static_cast<JacobiState *>(c.pinned);
@@ -1155,7 +1168,7 @@ int mk_dist_jacobi_solve(int R, mk_jacobi **solvers, mk_dist_matrix **A, mk_vect
       for (int r = 0; r < R; r++) {   // interior planes
         int nb = 0;
         MK_D(launch_jacobi_sweep(&A[r]->diag, b[r]->d, W[r].extra, cur[r], nxt[r], W[r].slab, &W[r].state->done, &nb, A[r]->gap0, A[r]->gap1,
-                                 pb[r], pe[r]));
+                                 pb[r], pe[r], imax[r]));
         blocks[r] = nb;
       }
       for (int r = 0; r < R; r++) {   // boundary planes once ghosts and off-rank product are in
@@ -1164,9 +1177,9 @@ int mk_dist_jacobi_solve(int R, mk_jacobi **solvers, mk_dist_matrix **A, mk_vect
         for (int q = 0; q < 2; q++) {
           if (ranges[q][1] <= ranges[q][0]) continue;
           int nb = 0;
-          if (blocks[r] >= kSlabStride - 8) { cleanup(); return fail(MK_ERR_UNSUPPORTED, "row-block Jacobi: too many reduction partials for a split sweep"); }
+          // fits by construction (set-up sized the interior launch around the boundary launches' needs); the launcher checks again
           MK_D(launch_jacobi_sweep(&A[r]->diag, b[r]->d, W[r].extra, cur[r], nxt[r], W[r].slab + blocks[r], &W[r].state->done, &nb, A[r]->gap0,
-                                   A[r]->gap1, ranges[q][0], ranges[q][1]));
+                                   A[r]->gap1, ranges[q][0], ranges[q][1], kSlabStride - blocks[r]));
           blocks[r] += nb;
         }
       }

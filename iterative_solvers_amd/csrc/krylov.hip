@@ -226,7 +226,8 @@ int mk_pcg_solve(mk_pcg *S, const mk_matrix *A, const mk_vector *b, mk_vector *x
   }
   if (S->print_level > 1 && S->norms && S->iterations >= 0 && S->iterations < S->norms_cap) {
     std::vector<double> h((size_t)S->iterations + 1);
-    MK_HIP(hipMemcpy(h.data(), S->norms, sizeof(double) * h.size(), hipMemcpyDeviceToHost));
+    MK_HIP(hipMemcpyAsync(h.data(), S->norms, sizeof(double) * h.size(), hipMemcpyDeviceToHost, c.stream));
+    MK_HIP(hipStreamSynchronize(c.stream));
     print_pcg_table(S->two_norm, h.data(), S->iterations, sqrt(hst[0].bi_prod));
   }
   return MK_OK;

@@ -54,12 +54,17 @@ Context &ctx();
 // Device memory comes from a caching allocator (context.hip): hipFree costs 0.2 ms a call on this stack whatever the size
 // (it waits for the device, then unmaps), and a conversion or a solver setup frees half a dozen arrays.  Blocks of 1 MB and
 // more go to a size-ordered free list instead and are handed out again to the next request they fit (at most 1/8 larger);
-// everything runs on the library's streams in order, so a recycled block is never touched by its old user's kernels after
-// its new user's.  The cache holds at most a quarter of the device's memory (MK_ALLOC_CACHE_MB), gives everything back
+// INVARIANT the reuse rests on: a block's old user and its new user are ordered on ctx().stream.  Work on any other
+// stream (RCCL communication streams, the local world's side stream) must be joined back into ctx().stream by events
+// before the API call that issued it returns; such streams are registered (register_side_stream) and cached_free waits
+// for any of them that is still busy before it keeps a block for reuse.  Host copies into fresh blocks go through
+// ctx().stream (hipMemcpyAsync + synchronize), never the null stream.  The cache holds at most a quarter of the device's memory (MK_ALLOC_CACHE_MB), gives everything back
 // before an allocation would fail and at mk_finalize(); MK_NO_ALLOC_CACHE=1 switches it off.
 void *cached_alloc(size_t bytes);
 void cached_free(void *p);
 void cache_release_all();
+void register_side_stream(hipStream_t s);
+void unregister_side_stream(hipStream_t s);
 template <typename T>
 int dev_alloc(T **p, size_t count) {
   *p = nullptr;
@@ -103,6 +108,11 @@ struct PcgState {
   int breakdown;   // 1 zero <s,p>, 2 subnormal alpha, 3 subnormal gamma
   int pad;
 };
+
+// grid-level reduction slabs: component k of block b lives at slab[k * stride + b]
+constexpr int kMaxParts = 4;
+constexpr int kSlabStride = 4096;  // >= any reduction grid we launch
+constexpr int kSplitChunk = 2048;  // entries per chunk of the split SpMV kernel
 
 // ---------------------------------------------------------------------------- objects
 }  // namespace mk
@@ -158,9 +168,7 @@ struct mk_matrix {
   bool sweep_auto = false;         // enough parallelism for the sweep kernel to be the default
   bool sweep_streamed = false;     // the plan matches column offsets only: values are streamed from val[] (spmv_vsweep_kernel)
   unsigned short *sweep_perm = nullptr;   // sweep kernel, rows of more than 8 entries: row pair each lane of a chunk owns (ncp x C/2)
-  mutable int vsweep_lds_set = 0;
   mutable int sweep_bpc[6] = {0, 0, 0, 0, 0, 0};
-  mutable int sweep_lds_set[6] = {0, 0, 0, 0, 0, 0};   // dynamic LDS above 48 KB needs a one-time opt-in per kernel
   bool sweep_diag_uniform = false; // every row has the (single) diagonal entry of the base pattern
   int npat = 0, pml = 0;
   int max_off = 0;                 // largest |column - row| over all patterns
@@ -180,11 +188,8 @@ struct mk_matrix {
 
 namespace mk {
 
-// grid-level reduction slabs: component k of block b lives at slab[k * stride + b]
-constexpr int kMaxParts = 4;
-constexpr int kSlabStride = 4096;  // >= any reduction grid we launch
-constexpr int kSplitChunk = 2048;  // entries per chunk of the split SpMV kernel
-
+// nonzero: the SpMV launchers work out their grid (*nblocks) and return without enqueueing anything
+int &dry_launch();
 int analyse_matrix(mk_matrix *A);
 int init_static_scratch(int device);   // spmv.hip: address of the file-scope scratch array of mk_spmv_dot_static on this GPU
 int ensure_dinv(mk_matrix *A);
@@ -201,7 +206,8 @@ int launch_spmv_dot(const mk_matrix *A, const double *x, double *y, double *slab
 // MK_ERR_UNSUPPORTED (no error text) when A is not served by the stream kernel
 int launch_jacobi_sweep(const mk_matrix *A, const double *rhs, const double *extra, const double *xold, double *xnew,
                         double *slab, const int *done, int *nblocks, int extra_gap0 = 0, int extra_gap1 = 0,
-                        int plane_begin = 0, int plane_end = 0);
+                        int plane_begin = 0, int plane_end = 0, int max_blocks = kSlabStride);
+int jacobi_sweep_blocks(const mk_matrix *A, int plane_begin, int plane_end, int max_blocks);
 // planes of the sweep plan (rows per plane, number of planes); 0 when the matrix is not served by the sweep kernel
 int sweep_planes(const mk_matrix *A, int *rows_per_plane, int *nplanes);
 

@@ -350,7 +350,8 @@ static int plan_sweep(mk_matrix *A, const std::vector<int> &tab, const std::vect
     const int64_t row0 = (int64_t)(S.K / 2) * S.P;
     const int64_t nrow = std::min<int64_t>(S.P, A->nrows - row0);
     std::vector<unsigned short> ids((size_t)std::max<int64_t>(nrow, 1));
-    MK_HIP(hipMemcpy(ids.data(), A->pat + row0, sizeof(unsigned short) * (size_t)nrow, hipMemcpyDeviceToHost));
+    MK_HIP(hipMemcpyAsync(ids.data(), A->pat + row0, sizeof(unsigned short) * (size_t)nrow, hipMemcpyDeviceToHost, ctx().stream));
+    MK_HIP(hipStreamSynchronize(ctx().stream));
     const unsigned fullm = len >= 32 ? 0xffffffffu : (1u << len) - 1u;
     std::vector<unsigned short> perm((size_t)S.ncp * T);
     for (int cp = 0; cp < S.ncp; cp++) {
@@ -364,7 +365,8 @@ static int plan_sweep(mk_matrix *A, const std::vector<int> &tab, const std::vect
         }
     }
     MK_TRY(dev_alloc(&A->sweep_perm, perm.size()));
-    MK_HIP(hipMemcpy(A->sweep_perm, perm.data(), sizeof(unsigned short) * perm.size(), hipMemcpyHostToDevice));
+    MK_HIP(hipMemcpyAsync(A->sweep_perm, perm.data(), sizeof(unsigned short) * perm.size(), hipMemcpyHostToDevice, ctx().stream));
+    MK_HIP(hipStreamSynchronize(ctx().stream));   // perm is a host temporary
   }
   // one diagonal entry in the base pattern and every row keeps it: 1/diag is one number (fused Jacobi-PCG step)
   int ndiag = 0;
@@ -703,6 +705,7 @@ static int launch_vector(const mk_matrix *A, double alpha, const double *x, doub
   int blocks = (int)std::min<int64_t>(std::max<int64_t>(want, 1), (int64_t)c.num_cus * 8);
   if (blocks > kSlabStride) blocks = kSlabStride;
   if (nblocks) *nblocks = blocks;
+  if (dry_launch()) return MK_OK;   // grid size only (mk_spmv_dot_static checks it against its scratch before anything is enqueued)
 #define MK_LAUNCH_G(GG)                                                                                      \
   case GG:                                                                                                   \
     hipLaunchKernelGGL((spmv_vector_kernel<GG, MODE>), dim3(blocks), dim3(kThreads), 0, c.stream, A->nrows, \
@@ -979,6 +982,7 @@ static int launch_stream_u(const mk_matrix *A, double alpha, const double *x, do
   blocks = std::max<int64_t>(8, blocks / 8 * 8);
   if (blocks > kSlabStride) blocks = kSlabStride;
   if (nblocks) *nblocks = (int)blocks;
+  if (dry_launch()) return MK_OK;   // grid size only (mk_spmv_dot_static checks it against its scratch before anything is enqueued)
   // Optional tiled traversal (MK_STREAM_TILE=<chunks>, off by default): measured on 7-pt 512^3 it is
   // 2-4 % SLOWER than the linear sweep (tile 16..128) although it removes the x re-fetches of the z+-1
   // planes: those re-fetches are served by the Infinity Cache and the tiling breaks up the value stream.
@@ -1260,6 +1264,7 @@ static int launch_pattern(const mk_matrix *A, double alpha, const double *x, dou
   blocks = std::max<int64_t>(8, blocks / 8 * 8);
   if (blocks > kSlabStride) blocks = kSlabStride;
   if (nblocks) *nblocks = (int)blocks;
+  if (dry_launch()) return MK_OK;   // grid size only (mk_spmv_dot_static checks it against its scratch before anything is enqueued)
   // plane-tiled traversal when the operator couples rows more than ~1.5 MB of x apart (3D grids):
   // tile_p = that stride in chunks, tile_t = chunks of one plane walked before moving to the next plane
   static const int env_tile = getenv("MK_PATTERN_TILE") ? atoi(getenv("MK_PATTERN_TILE")) : 0;
@@ -1686,28 +1691,18 @@ __global__ __launch_bounds__(T, T == 512 ? 2 : 1) void spmv_sweep_kernel(
   }
 }
 
-template <int MODE>
-static int launch_sweep(const mk_matrix *A, double alpha, const double *x, double beta, double *y, double *slab,
-                        const int *done, int *nblocks, const double *rhs = nullptr, const double *extra = nullptr,
-                        PcgState *st = nullptr, const double *slab_in = nullptr, int nblocks_in = 0, int stride_in = kSlabStride,
-                        double *xupd = nullptr, int flags = 0, double *norms = nullptr, int plane_begin = 0, int plane_end = 0) {
+// Segments a sweep launch over the planes of S cuts them into (grid = ncp * nseg blocks, rounded up to 8); 0 when even one
+// segment needs more than max_blocks reduction partials.  Shared by the launcher and by callers that must know the grid
+// before they launch (row-block Jacobi: the partials of its interior and boundary launches share one slab).
+static int sweep_segments(const mk_matrix *A, int mode, const SweepArgs &S, int max_blocks) {
   Context &c = ctx();
-  if (!A->sweep || A->sweep_streamed) return fail(MK_ERR_UNSUPPORTED, "spmv: the sweep kernel needs rows that are sub-lists of one (offsets, values) pattern with offsets a*P + b");
-  SweepArgs S = *A->sweep;
-  if (plane_end > plane_begin) {   // a caller's sub-range of the planes (row-block Jacobi: interior / boundary launches)
-    if (plane_begin < 0 || plane_end > S.K) return fail(MK_ERR_INVALID, "spmv: planes [%d, %d) of %d", plane_begin, plane_end, S.K);
-    S.kb = plane_begin;
-    S.K = plane_end - plane_begin;
-  }
   const size_t lds = (size_t)kSweepNS * S.sw * 8 + (size_t)A->npat * 4;
   static const int env_bpc = getenv("MK_SWEEP_BPC") ? atoi(getenv("MK_SWEEP_BPC")) : 0;
-  int per_cu = env_bpc > 0 ? env_bpc : A->sweep_bpc[MODE];
+  int per_cu = env_bpc > 0 ? env_bpc : A->sweep_bpc[mode];
   if (per_cu <= 0) {
-    int occ = 0;
-    hipError_t oe = hipSuccess;
-    occ = (S.C == 2048) ? 1 : (S.C == 1024) ? 2 : (int)std::min<size_t>(3, (size_t)(160 * 1024) / std::max<size_t>(lds, 1));   // LDS-bound: 160 KB per CU
-    per_cu = (oe == hipSuccess && occ > 0) ? std::min(occ, 8) : 2;
-    A->sweep_bpc[MODE] = per_cu;
+    const int occ = (S.C == 2048) ? 1 : (S.C == 1024) ? 2 : (int)std::min<size_t>(3, (size_t)(160 * 1024) / std::max<size_t>(lds, 1));   // LDS-bound: 160 KB per CU
+    per_cu = occ > 0 ? std::min(occ, 8) : 2;
+    A->sweep_bpc[mode] = per_cu;
   }
   // segments: fill the chip, but keep at least 8 planes per segment (each segment re-reads two halo planes)
   static const int env_nseg = getenv("MK_SWEEP_NSEG") ? atoi(getenv("MK_SWEEP_NSEG")) : 0;
@@ -1722,27 +1717,50 @@ static int launch_sweep(const mk_matrix *A, double alpha, const double *x, doubl
   static const int no_fit = getenv("MK_SWEEP_NO_FIT") ? atoi(getenv("MK_SWEEP_NO_FIT")) : 0;
   // Only the two CG sweeps (3 and 5 streams each) gain; SpMV+dot (x in, y out) measured 4-10 % SLOWER with the fit
   // (512^3 490 against 469 us, 27-point 256^3 159 against 144 us, banded 2^26 280 against 259 us).
-  if (env_nseg <= 0 && !no_fit && (MODE == 4 || MODE == 5)) {
+  if (env_nseg <= 0 && !no_fit && (mode == 4 || mode == 5)) {
     const int64_t fit = (int64_t)c.num_cus * std::max(1, 1024 / S.C);
     const int64_t k = fit / S.ncp;
     if (k >= 1 && k * S.ncp * 10 >= fit * 9 && S.K / k >= 8) nseg = (int)k;
   }
   nseg = std::min(nseg, std::max(1, S.K / 8));
   nseg = std::max(1, std::min(nseg, S.K));
-  while ((int64_t)S.ncp * nseg > kSlabStride - 8 && nseg > 1) nseg--;
-  if ((int64_t)S.ncp * nseg > kSlabStride - 8) return fail(MK_ERR_UNSUPPORTED, "spmv: sweep grid of %d chunks per plane is too large", S.ncp);
+  max_blocks = std::min(max_blocks, kSlabStride - 8);
+  while ((S.ncp * (int64_t)nseg + 7) / 8 * 8 > max_blocks && nseg > 1) nseg--;
+  if ((S.ncp * (int64_t)nseg + 7) / 8 * 8 > max_blocks) return 0;
+  return nseg;
+}
+
+template <int MODE>
+static int launch_sweep(const mk_matrix *A, double alpha, const double *x, double beta, double *y, double *slab,
+                        const int *done, int *nblocks, const double *rhs = nullptr, const double *extra = nullptr,
+                        PcgState *st = nullptr, const double *slab_in = nullptr, int nblocks_in = 0, int stride_in = kSlabStride,
+                        double *xupd = nullptr, int flags = 0, double *norms = nullptr, int plane_begin = 0, int plane_end = 0,
+                        int max_blocks = kSlabStride) {
+  Context &c = ctx();
+  if (!A->sweep || A->sweep_streamed) return fail(MK_ERR_UNSUPPORTED, "spmv: the sweep kernel needs rows that are sub-lists of one (offsets, values) pattern with offsets a*P + b");
+  SweepArgs S = *A->sweep;
+  if (plane_end > plane_begin) {   // a caller's sub-range of the planes (row-block Jacobi: interior / boundary launches)
+    if (plane_begin < 0 || plane_end > S.K) return fail(MK_ERR_INVALID, "spmv: planes [%d, %d) of %d", plane_begin, plane_end, S.K);
+    S.kb = plane_begin;
+    S.K = plane_end - plane_begin;
+  }
+  const size_t lds = (size_t)kSweepNS * S.sw * 8 + (size_t)A->npat * 4;
+  const int nseg = sweep_segments(A, MODE, S, max_blocks);
+  if (nseg < 1) return fail(MK_ERR_UNSUPPORTED, "spmv: sweep grid of %d chunks per plane does not fit %d reduction partials", S.ncp, max_blocks);
   S.nseg = nseg;
   const int blocks = (S.ncp * nseg + 7) / 8 * 8;
   if (nblocks) *nblocks = blocks;
+  if (dry_launch()) return MK_OK;   // grid size only (mk_spmv_dot_static checks it against its scratch before anything is enqueued)
   const int T = S.C / 2;
   const int nl = std::max(2, (S.sw + 2 * T - 1) / (2 * T));
   const bool nt = nt_rows(A->nrows);
 #define MK_LAUNCH_SW(NLL, TT)                                                                                              \
   {                                                                                                                        \
     auto kern = nt ? spmv_sweep_kernel<MODE, NLL, TT, true> : spmv_sweep_kernel<MODE, NLL, TT, false>;                     \
-    if (lds > 48 * 1024 && !A->sweep_lds_set[MODE]) {                                                                      \
+    static size_t lds_max[2] = {48 * 1024, 48 * 1024};   /* per kernel instance: only ever raised (the attribute is the kernel's, not the matrix's) */ \
+    if (lds > lds_max[nt ? 1 : 0]) {                                                                                       \
       MK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-      A->sweep_lds_set[MODE] = 1;                                                                                          \
+      lds_max[nt ? 1 : 0] = lds;                                                                                           \
     }                                                                                                                      \
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(TT), lds, c.stream, S, A->etab, A->nrows, A->ncols, A->pat,     \
                        A->pmask, A->npat, x, y, alpha, beta, slab, done, rhs, extra, st, slab_in, nblocks_in, stride_in,  \
@@ -2035,6 +2053,7 @@ static int launch_split(const mk_matrix *A, double alpha, const double *x, doubl
   const int main_blocks = std::max(1, std::min(A->nchunks, c.num_cus * 8));
   const int fix_blocks = std::max(1, std::min((A->nchunks + kThreads - 1) / kThreads, 1024));
   if (nblocks) *nblocks = main_blocks + fix_blocks;
+  if (dry_launch()) return MK_OK;   // grid size only (mk_spmv_dot_static checks it against its scratch before anything is enqueued)
   // R-MAT 2^28 entries, x = 134 MB: 3.96 -> 3.54 ms with the matrix stream nontemporal (fewer x gathers miss)
   const int *colv = A->col;
   const double *xg = x;
@@ -2071,16 +2090,30 @@ int launch_spmv(const mk_matrix *A, double alpha, const double *x, double beta, 
 // one Jacobi sweep through the stream kernel; returns MK_ERR_UNSUPPORTED when the matrix does not
 // use that kernel (the caller then runs its own lane-per-row sweep)
 int launch_jacobi_sweep(const mk_matrix *A, const double *rhs, const double *extra, const double *xold, double *xnew,
-                        double *slab, const int *done, int *nblocks, int extra_gap0, int extra_gap1, int plane_begin, int plane_end) {
+                        double *slab, const int *done, int *nblocks, int extra_gap0, int extra_gap1, int plane_begin, int plane_end,
+                        int max_blocks) {
   MK_TRY(analyse_matrix(const_cast<mk_matrix *>(A)));
   if (A->kernel == MK_SPMV_VSWEEP) return launch_vsweep(A, 2, 1.0, xold, 0.0, xnew, slab, done, nblocks, rhs, extra);
   if (A->kernel == MK_SPMV_SWEEP)   // rows [extra_gap0, extra_gap1) have extra == 0: the kernel reads one pair for all of them
     return launch_sweep<2>(A, 1.0, xold, 0.0, xnew, slab, done, nblocks, rhs, extra, nullptr, nullptr, (extra_gap0 + 1) & ~1, extra_gap1,
-                           nullptr, 0, nullptr, plane_begin, plane_end);
+                           nullptr, 0, nullptr, plane_begin, plane_end, max_blocks);
   if (plane_end > plane_begin) return fail(MK_ERR_UNSUPPORTED, "jacobi sweep: plane ranges need the sweep kernel");
   if (A->kernel == MK_SPMV_PATTERN) return launch_pattern<2>(A, 1.0, xold, 0.0, xnew, slab, done, nblocks, rhs, extra);
   if (A->kernel != MK_SPMV_STREAM) return MK_ERR_UNSUPPORTED;
   return launch_stream<2>(A, 1.0, xold, 0.0, xnew, slab, done, nblocks, rhs, extra);
+}
+
+// blocks (= reduction partials) a Jacobi sweep over planes [plane_begin, plane_end) launches when at most max_blocks slots
+// are left in the caller's slab; 0 when it does not fit.  No launch, no allocation: the row-block solver decides at
+// set-up whether its interior + boundary launches fit one slab.
+int jacobi_sweep_blocks(const mk_matrix *A, int plane_begin, int plane_end, int max_blocks) {
+  if (A->kernel != MK_SPMV_SWEEP || !A->sweep || A->sweep_streamed) return 0;
+  SweepArgs S = *A->sweep;
+  if (plane_begin < 0 || plane_end > S.K || plane_end <= plane_begin) return 0;
+  S.kb = plane_begin;
+  S.K = plane_end - plane_begin;
+  const int nseg = sweep_segments(A, 2, S, max_blocks);
+  return nseg < 1 ? 0 : (S.ncp * nseg + 7) / 8 * 8;
 }
 
 int sweep_planes(const mk_matrix *A, int *rows_per_plane, int *nplanes) {
@@ -2202,17 +2235,24 @@ int mk_spmv_dot_static(const mk_matrix *A, const mk_vector *x, mk_vector *y, dou
   // the analysis (row-length histogram, pattern tables, chunk starts) allocates: it must have run before
   if (!A->analysed) return fail(MK_ERR_INVALID, "mk_spmv_dot_static: matrix not analysed yet; call mk_matrix_get_info (it allocates) first");
   double *slab = sp, *out2 = sp + kStaticSlab, *carry = sp + kStaticSlab + 8;
-  int nb = 0;
   if (A->kernel == MK_SPMV_SPLIT) {
     if (!A->chunk_row) return fail(MK_ERR_INVALID, "mk_spmv_dot_static: the split kernel's chunk table is built (allocated) by the first mk_spmv / mk_spmv_dot; run one first");
     if (A->nchunks > kStaticCarryChunks)
       return fail(MK_ERR_UNSUPPORTED, "mk_spmv_dot_static: %lld entries in %d chunks exceed the static scratch (split-kernel matrices up to %lld entries)",
                   (long long)A->nnz, A->nchunks, (long long)kStaticCarryChunks * kSplitChunk);
-    MK_TRY(launch_split<1>(A, 1.0, x->d, 0.0, y->d, slab, nullptr, &nb, carry, true));
-  } else {
-    MK_TRY(launch_spmv_dot(A, x->d, y->d, slab, nullptr, &nb));
   }
-  if (nb > kSlabStride) return fail(MK_ERR_UNSUPPORTED, "mk_spmv_dot_static: %d reduction partials, the static scratch holds %d", nb, kSlabStride);
+  // two passes over the same launcher: the first only works out the grid (nothing is enqueued), so that the number of
+  // reduction partials is checked against the static slab BEFORE any kernel can write there
+  int nb = 0;
+  for (int pass = 0; pass < 2; pass++) {
+    dry_launch() = (pass == 0);
+    int rc;
+    if (A->kernel == MK_SPMV_SPLIT) rc = launch_split<1>(A, 1.0, x->d, 0.0, y->d, slab, nullptr, &nb, carry, true);
+    else rc = launch_spmv_dot(A, x->d, y->d, slab, nullptr, &nb);
+    dry_launch() = 0;
+    MK_TRY(rc);
+    if (nb < 1 || nb > kSlabStride) return fail(MK_ERR_UNSUPPORTED, "mk_spmv_dot_static: %d reduction partials, the static scratch holds %d", nb, kSlabStride);
+  }
   if (!ytx && !xtx) return MK_OK;
   hipLaunchKernelGGL(finish_dot_kernel, dim3(1), dim3(kThreads), 0, c.stream, slab, nb, out2);
   double *h = static_cast<double *>(c.pinned);   // pinned at mk_init: the copy needs no staging allocation

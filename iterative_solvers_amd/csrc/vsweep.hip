@@ -277,8 +277,13 @@ static int launch_vsweep_t(const mk_matrix *A, const SweepArgs &S, size_t lds, i
                            double *y, double *slab, const int *done, const double *rhs, const double *extra) {
   Context &c = ctx();
   auto kern = nt ? spmv_vsweep_kernel<MODE, NL, NVL, T, true> : spmv_vsweep_kernel<MODE, NL, NVL, T, false>;
-  if (lds > 48 * 1024)   // dynamic LDS above 48 KB needs an opt-in per kernel (cheap, no allocation)
+  // dynamic LDS above 48 KB needs an opt-in per kernel (no allocation).  The attribute belongs to the kernel, not to the
+  // matrix: it is only ever raised, so a matrix with a smaller stage cannot lower it under one with a larger stage.
+  static size_t lds_max[2] = {48 * 1024, 48 * 1024};   // per template instance and cache policy
+  if (lds > lds_max[nt ? 1 : 0]) {
     MK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    lds_max[nt ? 1 : 0] = lds;
+  }
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(T), lds, c.stream, S, A->etab, A->nrows, A->ncols, A->nnz, A->pat, A->pmask,
                      A->npat, A->rowptr, A->val, x, y, alpha, beta, slab, done, rhs, extra);
   MK_HIP(hipGetLastError());
@@ -308,6 +313,7 @@ static int launch_vsweep_m(const mk_matrix *A, double alpha, const double *x, do
   S.nseg = nseg;
   const int blocks = (S.ncp * nseg + 7) / 8 * 8;
   if (nblocks) *nblocks = blocks;
+  if (dry_launch()) return MK_OK;
   const int nl = std::max(2, (S.sw + 2 * T - 1) / (2 * T));
   const bool nt = nt_rows(A->nrows) || nt_matrix((double)A->nnz * 8.0);
 #define MK_VS(NLL, NVV, TT) return launch_vsweep_t<MODE, NLL, NVV, TT>(A, S, lds, blocks, nt, alpha, x, beta, y, slab, done, rhs, extra);

@@ -24,3 +24,18 @@ def test_bench_refuses_a_mismatched_launcher():
     env = dict(os.environ, WORLD_SIZE="3", RANK="0", MK_BENCH_DRY_SPAWN="1")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=120)
     assert out.returncode != 0 and "WORLD_SIZE=3" in out.stderr
+
+
+def test_bench_ends_when_one_rank_dies():
+    """ADVICE r2 / VERDICT r2 item 1a: a rank other than 0 dies while the rest wait in a collective; the parent must notice,
+    terminate the others and fail with that rank's stderr instead of blocking until the driver's timeout."""
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(MK_BENCH_DRY_SPAWN="1", MK_BENCH_DRY_FAIL_RANK="1")
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--steps", "3", "--warmup", "1"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 7, (out.returncode, out.stderr[-2000:])
+    assert "rank 1 of 3 exited with code 7" in out.stderr and "fails on purpose" in out.stderr
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert time.time() - t0 < 120

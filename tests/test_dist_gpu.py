@@ -325,10 +325,14 @@ def blocks(rp, ci, v, n, rs, comms):
         blk = mk.Matrix.from_csr(hi - lo, n, (rp[lo:hi + 1] - rp[lo]).astype(np.int32), ci[rp[lo]:rp[hi]], v[rp[lo]:rp[hi]])
         out.append(mkd.DistMatrix(blk, n, rs, comms[r]))
     return out
-cases = [("banded", 60000, np.array([0, 20000, 41000, 60000], np.int64), 10),      # uneven blocks
-         ("banded", 40001, np.array([0, 10000, 20000, 30000, 40001], np.int64), 1),
-         ("lap7", (12, 10, 60), None, 5)]
-for kind, shape, rs, every in cases:
+cases = [("banded", 60000, np.array([0, 20000, 41000, 60000], np.int64), 10, 1e-9),      # uneven blocks
+         ("banded", 40001, np.array([0, 10000, 20000, 30000, 40001], np.int64), 1, 1e-9),
+         ("lap7", (12, 10, 60), None, 5, 1e-9),
+         # ADVICE r2: planes of 1408 chunks of 512 rows.  A middle rank's interior launch + two boundary launches would need
+         # 3 x 1408 = 4224 slots of the 4096-slot slab: set-up must size the interior launch around the boundary launches
+         # (or keep the one-launch sweep), never write past the slab or fail in the loop
+         ("lap7", (256, 2816, 30), None, 5, 1e-2)]
+for kind, shape, rs, every, tol in cases:
     if kind == "banded":
         n = shape
         rp, ci, v = oracle.banded_csr(n, 3)
@@ -337,7 +341,7 @@ for kind, shape, rs, every in cases:
         n = rp.size - 1
         v = v.copy(); v[ci == np.repeat(np.arange(n), np.diff(rp))] += 1.0      # strictly dominant
         rs = mkd.slab_row_start(*shape, 3)
-    o = oracle.jacobi(rp, ci, v, np.ones(n), tol=1e-9, maxit=300, check_every=every)
+    o = oracle.jacobi(rp, ci, v, np.ones(n), tol=tol, maxit=300, check_every=every)
     comms = mkd.Comm.local_world(len(rs) - 1)
     As = blocks(rp, ci, v, n, rs, comms)
     for a in As:
@@ -345,7 +349,7 @@ for kind, shape, rs, every in cases:
     assert all(a.diag_info().kernel == mk.SPMV_SWEEP for a in As), [a.diag_info().kernel for a in As]
     bs = [a.vector(fill=1.0) for a in As]
     xs = [a.vector(fill=0.0) for a in As]
-    Ss = [mk.Jacobi(max_iter=300, tol=1e-9, check_every=every) for _ in As]
+    Ss = [mk.Jacobi(max_iter=300, tol=tol, check_every=every) for _ in As]
     res = mkd.dist_jacobi_solve(Ss, As, bs, xs)
     assert res[0]["converged"] == o["converged"] and res[0]["iterations"] == o["iterations"], (kind, res[0], o["iterations"])
     assert np.isclose(res[0]["rel_res_norm"], o["rel_res_norm"], rtol=1e-9)
@@ -364,7 +368,7 @@ def test_dist_jacobi_split_sweep_matches_oracle(split):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, MK_JACOBI_SPLIT=split)
-    out = subprocess.run([sys.executable, "-c", _SPLIT_SNIPPET, root], capture_output=True, text=True, timeout=300, env=env)
+    out = subprocess.run([sys.executable, "-c", _SPLIT_SNIPPET, root], capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0 and "split ok" in out.stdout, out.stderr[-3000:]
 
 

@@ -472,3 +472,58 @@ def test_bench_cpu_configs_mode_runs_config_1():
         assert abs(t["cpu_iterations"] - t["gpu_iterations"]) <= 2
         assert t["gpu_it_per_s"] > t["cpu_it_per_s"] > 0
         assert t["gpu_rel_res"] < float(tol[3:]) and t["cpu_rel_res"] < float(tol[3:])
+
+
+@pytest.mark.gpu
+def test_driver_config_1_full_size_through_the_mtx_path(tmp_path):
+    """BASELINE configs[0] as the reference runs it (sparse_matrix.c:228-376 -> solvers.c -solver 50): 2D 5-point Poisson
+    1024^2 written as a Matrix Market file (5.2 M entries), read back by the loader -- large enough that the PARALLEL parser
+     is the one that runs, which the trace line proves --, sorted and converted on the device, solved by
+    unpreconditioned CG at the reference's default tolerance; iteration count within 2 of the oracle's orc_pcg on the same
+    operator (parity unpinned: no HYPRE here), residual below the tolerance."""
+    L = _host()
+    L.write_stencil_mtx.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int]
+    mtx = tmp_path / "poisson1024.mtx"
+    assert L.write_stencil_mtx(str(mtx).encode(), 5, 1024, 1024, 1) == 0
+    env = dict(os.environ, MK_PARSE_TRACE="1")
+    env.pop("MK_PARSE_MIN_ENTRIES", None)
+    env.pop("MK_PARSE_THREADS", None)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    out = subprocess.run([os.path.join(HOST, "solver"), "-solver", "50", "-mtx", str(mtx), "-tol", "1e-6", "-maxit", "5000", "-log", "0"],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert re.search(r"Matrix Market parser: parallel \(5238784 entries, \d+ threads\)", out.stderr), out.stderr[-2000:]
+    it = int(re.search(r"^Iterations = (\d+)$", out.stdout, re.M).group(1))
+    nrm = float(re.search(r"^Final Relative Residual Norm = ([0-9.e+-]+)$", out.stdout, re.M).group(1))
+    rp, ci, v = oracle.stencil_csr(5, 1024, 1024, 1)
+    o = oracle.pcg(rp, ci, v, np.ones(rp.size - 1), tol=1e-6, maxit=5000, omp=True)
+    assert abs(it - o["iterations"]) <= 2, (it, o["iterations"])
+    assert nrm < 1e-6 and abs(nrm - o["rel_res_norm"]) <= 1e-3 * o["rel_res_norm"]
+
+
+@pytest.mark.gpu
+def test_driver_reads_a_shuffled_symmetric_file_with_the_parallel_parser(tmp_path):
+    """the parallel parser inside the GPU suite on a file the serial one would also take: symmetric storage (lower triangle,
+    shuffled), 359 k stored entries -> 599 k after expansion; the driver's answer must be the one the oracle gives for the
+    expanded operator."""
+    nx, ny = 400, 300
+    rp, ci, v = oracle.stencil_csr(5, nx, ny)
+    n = rp.size - 1
+    rows = np.repeat(np.arange(n), np.diff(rp))
+    low = ci <= rows
+    r, c, vv = rows[low], ci[low], v[low]
+    order = np.random.default_rng(5).permutation(r.size)
+    mtx = tmp_path / "sym.mtx"
+    with open(mtx, "w") as f:
+        f.write("%%MatrixMarket matrix coordinate real symmetric\n")
+        f.write(f"{n} {n} {r.size}\n")
+        f.write("".join(f"{r[k] + 1} {c[k] + 1} {vv[k]:.1f}\n" for k in order))
+    env = dict(os.environ, MK_PARSE_TRACE="1", MK_PARSE_THREADS="6")
+    env.pop("MK_PARSE_MIN_ENTRIES", None)
+    out = subprocess.run([os.path.join(HOST, "solver"), "-solver", "51", "-mtx", str(mtx), "-tol", "1e-8", "-maxit", "3000", "-log", "0"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "Matrix Market parser: parallel" in out.stderr
+    it = int(re.search(r"^Iterations = (\d+)$", out.stdout, re.M).group(1))
+    o = oracle.pcg(rp, ci, v, np.ones(n), tol=1e-8, precond=1, maxit=3000)
+    assert abs(it - o["iterations"]) <= 2, (it, o["iterations"])

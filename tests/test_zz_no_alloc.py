@@ -73,3 +73,42 @@ def test_spmv_dot_static_rejects_what_the_scratch_cannot_hold():
     assert A.spmv_dot(x, y)[1] == float(n)           # the allocating entry point still serves it
     with pytest.raises(mk.MkError, match="alias"):
         A.spmv_dot_static(x, x)
+
+
+CHILD = r"""
+import sys
+sys.path.insert(0, sys.argv[1])
+sys.path.insert(0, sys.argv[1] + "/tests")
+import numpy as np
+import iterative_solvers_amd as mk
+import test_zz_no_alloc as T
+mk.init(0)
+for case in ["sweep", "pattern", "stream", "vsweep", "vector", "split"]:
+    A, xh = T._matrix(case, 1)
+    n = A.nrows
+    x, y = mk.Vector(n, values=xh), mk.Vector(n)
+    A.info()
+    A.spmv_dot_static(x, y)            # first call of the process on this kernel (one-time attribute set-up, no memory)
+    mk.synchronize()
+    before = mk.memory_info() + mk.memory_calls()
+    for _ in range(3):
+        A.spmv_dot_static(x, y)
+    mk.synchronize()
+    after = mk.memory_info() + mk.memory_calls()
+    assert before == after, (case, before, after)
+print("no allocation seen")
+"""
+
+
+@pytest.mark.parametrize("no_cache", ["0", "1"])
+def test_spmv_dot_static_allocates_nothing(no_cache):
+    """the property the entry point exists for: the library's allocator sees no request and no release across the
+    call -- every block it hands out or takes back goes through cached_alloc / cached_free, which mk_memory_calls counts --
+    with the caching allocator on and off (the switch is read at mk_init, hence the child process)."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, MK_NO_ALLOC_CACHE=no_cache)
+    out = subprocess.run([sys.executable, "-c", CHILD, ROOT], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "no allocation seen" in out.stdout, out.stderr[-3000:]
