@@ -25,8 +25,8 @@ namespace mk {
 
 static void pcg_release(mk_pcg *S) {
   dev_free(S->r); dev_free(S->p); dev_free(S->s); dev_free(S->slab1); dev_free(S->slab2);
-  dev_free(S->state); dev_free(S->norms);
-  S->r = S->p = S->s = S->slab1 = S->slab2 = S->norms = nullptr;
+  dev_free(S->state); dev_free(S->norms); dev_free(S->p2);
+  S->r = S->p = S->s = S->slab1 = S->slab2 = S->norms = S->p2 = nullptr;
   S->state = nullptr;
   for (int k = 0; k < 2; k++)
     if (S->ev[k]) { (void)hipEventDestroy(S->ev[k]); S->ev[k] = nullptr; }
@@ -86,6 +86,7 @@ int mk_pcg_setup(mk_pcg *S, const mk_matrix *A, const mk_vector *b, const mk_vec
   for (int k = 0; k < 2; k++) MK_HIP(hipEventCreateWithFlags(&S->ev[k], hipEventDisableTiming));
   MK_TRY(analyse_matrix(const_cast<mk_matrix *>(A)));
   if (S->precond == MK_PRECOND_JACOBI) MK_TRY(ensure_dinv(const_cast<mk_matrix *>(A)));
+  if (A->kernel == MK_SPMV_VSWEEP) MK_TRY(dev_alloc(&S->p2, (size_t)S->n));   // K3 folded into the product writes p' to the other buffer
   MK_HIP(hipStreamSynchronize(ctx().stream));
   return MK_OK;
 }
@@ -142,10 +143,15 @@ int mk_pcg_solve(mk_pcg *S, const mk_matrix *A, const mk_vector *b, mk_vector *x
   double zscale = 1.0;
   static const int no_pfuse = getenv("MK_NO_FUSED_K3") ? atoi(getenv("MK_NO_FUSED_K3")) : 0;
   const bool fuse_p = fused && !no_pfuse && (!dinv || sweep_uniform_diag(A, &zscale));
+  // Variable-coefficient grids (vsweep kernel): K1 and K2 stay (the values cannot be streamed twice), K3 rides in K1's
+  // window fill from the second iteration on: p' = z + beta p goes to the other p buffer while the window is loaded.
+  // 12 nnz + 86 n bytes of the CSR model's 12 nnz + 92 n, and one launch less.
+  const bool vfuse = (A->kernel == MK_SPMV_VSWEEP) && !no_fused && !no_pfuse && S->p2 != nullptr;
+  if (vfuse) palt = S->p2;
   int nb2 = 0;
   // kernel timing: an event in front of every kernel of iterations 1 .. kTimedIters (the first iteration runs another
   // first kernel on the fused path) and one behind the last of them
-  const int nslots = fused ? (fuse_p ? 2 : 3) : 3;
+  const int nslots = fused ? (fuse_p ? 2 : 3) : (vfuse ? 2 : 3);
   const int timed_iters = S->timing ? std::min(mk_pcg::kTimedIters, S->max_iter - 1) : 0;
   if (timed_iters > 0 && S->tev.empty()) {
     S->tev.resize((size_t)mk_pcg::kTimedIters * mk_pcg::kTimedSlots + 1, nullptr);
@@ -174,6 +180,20 @@ int mk_pcg_solve(mk_pcg *S, const mk_matrix *A, const mk_vector *b, mk_vector *x
         else
           hipLaunchKernelGGL((pcg_update_p_kernel<false>), dim3(vb), dim3(kVecThreads), 0, c.stream, n, S->r, dinv, pcur, S->slab2, nb2, kSlabStride, S->two_norm, S->rel_change, S->state, S->norms, vec_flags(n));
       }
+    } else if (vfuse) {
+      if (it > 0) {
+        MK_TRY(launch_vsweep_cg_pdots(A, S->r, pcur, palt, dinv, S->s, S->slab2, vb, kSlabStride, S->slab1, S->state, S->two_norm,
+                                      S->rel_change, S->norms, &nb1));
+        std::swap(pcur, palt);
+      } else {
+        MK_TRY(launch_spmv_dot(A, pcur, S->s, S->slab1, &S->state->done, &nb1));
+      }
+      stamp(it);
+      if (dinv)
+        hipLaunchKernelGGL((pcg_update_xr_kernel<true>), dim3(vb), dim3(kVecThreads), 0, c.stream, n, pcur, S->s, dinv, x->d, S->r, S->slab1, nb1, kSlabStride, S->slab2, S->state, vec_flags(n));
+      else
+        hipLaunchKernelGGL((pcg_update_xr_kernel<false>), dim3(vb), dim3(kVecThreads), 0, c.stream, n, pcur, S->s, dinv, x->d, S->r, S->slab1, nb1, kSlabStride, S->slab2, S->state, vec_flags(n));
+      nb2 = vb;
     } else {
     MK_TRY(launch_spmv_dot(A, S->p, S->s, S->slab1, &S->state->done, &nb1));
     stamp(it);
@@ -203,7 +223,7 @@ int mk_pcg_solve(mk_pcg *S, const mk_matrix *A, const mk_vector *b, mk_vector *x
     }
   }
   if (tev_used > 0 && tev_used == timed_iters * nslots) (void)hipEventRecord(S->tev[tev_used++], c.stream);   // solve ended with the timed window
-  if (fuse_p && S->max_iter > 0)   // the test that the next step's first kernel would have made (K3's prologue; n = 0: no p update)
+  if ((fuse_p || vfuse) && S->max_iter > 0)   // the test that the next step's first kernel would have made (K3's prologue; n = 0: no p update)
     hipLaunchKernelGGL((pcg_update_p_kernel<false>), dim3(1), dim3(kVecThreads), 0, c.stream, (int64_t)0, S->r, (const double *)nullptr, pcur, S->slab2, nb2, kSlabStride, S->two_norm, S->rel_change, S->state, S->norms, 0);
   MK_HIP(hipGetLastError());
   MK_HIP(hipMemcpyAsync(&hst[0], S->state, sizeof(PcgState), hipMemcpyDeviceToHost, c.stream));

@@ -272,7 +272,7 @@ struct mk_pcg {
   int check_every = 16;
   // work space (setup)
   int64_t n = 0;
-  double *r = nullptr, *p = nullptr, *s = nullptr;
+  double *r = nullptr, *p = nullptr, *s = nullptr, *p2 = nullptr;
   double *slab1 = nullptr, *slab2 = nullptr;
   mk::PcgState *state = nullptr;
   double *norms = nullptr;

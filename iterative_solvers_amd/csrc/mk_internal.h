@@ -232,6 +232,12 @@ int launch_sweep_cg_resid_x(const mk_matrix *A, const double *p, double *r, doub
 int launch_vsweep(const mk_matrix *A, int mode, double alpha, const double *x, double beta, double *y, double *slab, const int *done,
                   int *nblocks, const double *rhs, const double *extra);
 
+// CG step on vsweep matrices: K3 (p' = z + beta p, z = r or r * dinv) rides in the window fill of the product;
+// s = A p', partials of <s,p'>, <p',p'>; prologue = K3's convergence test on the 3 components of slab_in
+int launch_vsweep_cg_pdots(const mk_matrix *A, const double *r, const double *p_old, double *p_new, const double *dinv, double *s,
+                           const double *slab_in, int nblocks_in, int stride_in, double *slab_out, PcgState *st, int two_norm,
+                           int rel_change, double *norms, int *nblocks);
+
 int exclusive_scan_u32(const uint32_t *in, uint32_t *out, size_t n, uint32_t *total_out_dev);
 
 // device COO -> CSR (stable by row).  Takes ownership of rows/cols/vals buffers of `coo`

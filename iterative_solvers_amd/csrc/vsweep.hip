@@ -15,6 +15,8 @@
 // Rows are summed left to right over the same (value, x) pairs as the CSR arrays hold, so the result equals the serial
 // reference's bit for bit (same rounding sequence).  Algorithmic bytes: SURVEY 8(d)'s 12 nnz + 20 n + 4; read here:
 // 8 nnz + 22 n.
+#include <cfloat>
+
 #include "mk_internal.h"
 
 namespace mk {
@@ -41,14 +43,21 @@ __device__ __forceinline__ d2u_t vs_ld_u(const d2u_t *ptr) {   // keeps the 8-by
 
 // MODE 0: y = alpha A x + beta y.  1: y = A x, partials of <y,x>, <x,x>.  2: Jacobi sweep y = x + D^-1 (rhs - extra - A x),
 // partial of ||rhs - extra - A x||^2, D picked up from the row's own entry with offset 0 (the last one stored).
+// MODE 3 (CG, first kernel of every step but the first): K3 rides in the window fill, as in spmv_sweep_kernel MODE 5.
+//   Prologue = K3's (gamma', hypre's convergence test, beta from the partials in slab_in).  The window is filled with
+//   p' = z + beta x instead of x (x = the old p; z = rhs, the residual, times `extra` = 1/diag per row when the Jacobi
+//   preconditioner is on: a third window stream), the block's own rows of p' go to pnew, then as MODE 1 on p':
+//   y = A p', partials of <y,p'>, <p',p'>.  flags: bit 0 two_norm, bit 1 rel_change.
 // NL = 16-byte ring loads per thread per slab = ceil(sw / 2T); NVL = 16-byte value loads per thread per plane-step
 // (NVL * 2T >= len * C entries).
-template <int MODE, int NL, int NVL, int T, bool NT>
+template <int MODE, int NL, int NVL, int T, bool NT, bool PRE>
 __global__ __launch_bounds__(T, 2) void spmv_vsweep_kernel(
     const SweepArgs S, const SweepEntry *__restrict__ etab, int64_t nrows, int64_t ncols, int64_t nnz,
     const unsigned short *__restrict__ pat, const unsigned *__restrict__ pmask, int npat, const int *__restrict__ rowptr,
     const double *__restrict__ val, const double *__restrict__ x, double *__restrict__ y, double alpha, double beta,
-    double *__restrict__ slab, const int *__restrict__ done, const double *__restrict__ rhs, const double *__restrict__ extra) {
+    double *__restrict__ slab, const int *__restrict__ done, const double *__restrict__ rhs, const double *__restrict__ extra,
+    PcgState *st, const double *__restrict__ slab_in, int nblocks_in, int stride_in, double *__restrict__ pnew, int flags,
+    double *__restrict__ norms) {
   if (done != nullptr && *done != 0) return;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   constexpr int C = 2 * T, NS = kNS, VCAP = NVL * 2 * T;
@@ -57,6 +66,33 @@ __global__ __launch_bounds__(T, 2) void spmv_vsweep_kernel(
   double *sval = ring + NS * sw;                                 // VCAP + 8 entries: the values of one plane-step
   unsigned *smask = reinterpret_cast<unsigned *>(sval + VCAP + 8);   // npat
   const int tid = threadIdx.x;
+  if (MODE == 3) {   // K3's prologue (krylov_kernels.h pcg_update_p_kernel), every block the same bits
+    if (block_flag_raised(&st->done)) return;
+    const bool leader = (blockIdx.x == 0 && tid == 0);
+    double d[3];
+    reduce_slab<3, T>(slab_in, nblocks_in, stride_in, d, ring);
+    const double gamma_new = d[0];
+    const double i_prod = (flags & 1) ? d[1] : d[0];
+    const double xx = d[2];
+    const double bi_prod = st->bi_prod, eps = st->eps, al = st->alpha, pp = st->pp, gamma_old = st->gamma_old;
+    __syncthreads();
+    bool conv = (i_prod / bi_prod < eps);
+    if (conv && (flags & 2) && i_prod > 0.0) {
+      const double ratio = al * al * pp / xx;
+      if (ratio >= eps) conv = false;
+    }
+    const bool tiny_gamma = (gamma_new < DBL_MIN) && (-gamma_new < DBL_MIN);
+    if (leader) {
+      st->gamma = gamma_new;
+      st->i_prod = i_prod;
+      if (norms) norms[st->iter] = sqrt(i_prod / bi_prod);
+      if (conv) { st->converged = 1; st->done = 1; }
+      else if (tiny_gamma) { st->breakdown = 3; st->done = 2; }
+    }
+    if (conv || tiny_gamma) return;
+    beta = gamma_new / gamma_old;
+    __syncthreads();   // ring was reduction scratch
+  }
   for (int i = tid; i < npat; i += T) smask[i] = pmask[i];
   const int nb = gridDim.x;   // multiple of 8; blocks of one XCD take neighbouring chunks of a plane (shared halos in its L2)
   const int lid = (blockIdx.x & 7) * (nb >> 3) + (blockIdx.x >> 3);
@@ -73,19 +109,40 @@ __global__ __launch_bounds__(T, 2) void spmv_vsweep_kernel(
     const int rlast = (nr - 1) & ~1;
     const int elast = (int)max((int64_t)0, nnz - 1);   // val[elast + 1] is allocation slack (dev_alloc): never used by a row
 
-    auto load_slab = [&](int j, d2_t(&reg)[NL]) {   // window of plane j
+    constexpr int NLR = (MODE == 3) ? NL : 1;              // second window stream (the residual) only in MODE 3
+    constexpr int NLD = (MODE == 3 && PRE) ? NL : 1;       // third (1/diag per row) with the Jacobi preconditioner
+    auto load_slab = [&](int j, d2_t(&reg)[NL], d2_t(&regr)[NLR], d2_t(&regd)[NLD]) {   // window of plane j
       const int g0 = min(j, k1) * S.P + r0 - S.wlo + lr;
 #pragma unroll
       for (int i = 0; i < NL; i++) {
         const int g = min(max(g0 + i * 2 * T, 0), xlast);
         reg[i] = *reinterpret_cast<const d2_t *>(reinterpret_cast<const char *>(x) + ((unsigned)g << 3));
+        if (MODE == 3) regr[i] = *reinterpret_cast<const d2_t *>(reinterpret_cast<const char *>(rhs) + ((unsigned)g << 3));
+        if (MODE == 3 && PRE) regd[i] = *reinterpret_cast<const d2_t *>(reinterpret_cast<const char *>(extra) + ((unsigned)g << 3));
       }
     };
-    auto write_slab = [&](int slot, const d2_t(&reg)[NL]) {
+    auto write_slab = [&](int slot, int j, const d2_t(&reg)[NL], const d2_t(&regr)[NLR], const d2_t(&regd)[NLD]) {
       double *dst = ring + slot * sw + lr;
 #pragma unroll
-      for (int i = 0; i < NL; i++)
-        if (lr + i * 2 * T < sw) *reinterpret_cast<d2_t *>(dst + i * 2 * T) = reg[i];
+      for (int i = 0; i < NL; i++) {
+        const int wi = lr + i * 2 * T;   // position in the window
+        if (wi < sw) {
+          d2_t v = reg[i];
+          if (MODE == 3) {
+            d2_t z = regr[i];
+            if (PRE) { z.x *= regd[i].x; z.y *= regd[i].y; }
+            v.x = beta * v.x + z.x;   // K3: p = beta p + z
+            v.y = beta * v.y + z.y;
+            const int own = wi - S.wlo;   // the block's own rows of its own planes go to the new p
+            if (j >= k0 && j < k1 && own >= 0 && own < rows_here) {
+              const int g = j * S.P + r0 + own;
+              if (g + 1 < nr) vs_st<NT>(reinterpret_cast<d2_t *>(reinterpret_cast<char *>(pnew) + ((unsigned)g << 3)), v);
+              else if (g < nr) *reinterpret_cast<double *>(reinterpret_cast<char *>(pnew) + ((unsigned)g << 3)) = v.x;
+            }
+          }
+          *reinterpret_cast<d2_t *>(dst + i * 2 * T) = v;
+        }
+      }
     };
     // first value of the chunk's rows in plane j (uniform over the block: scalar loads)
     auto span_begin = [&](int j) -> int { return rowptr[min(min(j, k1) * S.P + r0, nr)]; };
@@ -131,16 +188,16 @@ __global__ __launch_bounds__(T, 2) void spmv_vsweep_kernel(
 
     // register stages, used in place: ring stage (k mod 3) holds slab k+2 at step k; value stage ((k+1) mod 3) holds the
     // values of plane k+1 at step k, is written to LDS behind the step's first barrier and re-loaded with plane k+4
-    d2_t st0[NL], st1[NL], st2[NL];
+    d2_t st0[NL], st1[NL], st2[NL], rt0[NLR], rt1[NLR], rt2[NLR], dt0[NLD], dt1[NLD], dt2[NLD];
     d2u_t vs0[NVL], vs1[NVL], vs2[NVL];
     int vb0 = span_begin(k0), vb1 = span_begin(k0 + 1), vb2 = span_begin(k0 + 2);
-    load_slab(k0 - 1, st0);
-    load_slab(k0, st1);
-    load_slab(k0 + 1, st2);
+    load_slab(k0 - 1, st0, rt0, dt0);
+    load_slab(k0, st1, rt1, dt1);
+    load_slab(k0 + 1, st2, rt2, dt2);
     load_vals(vb0, vs0);
-    write_slab(0, st0);
-    write_slab(1, st1);
-    write_slab(2, st2);
+    write_slab(0, k0 - 1, st0, rt0, dt0);
+    write_slab(1, k0, st1, rt1, dt1);
+    write_slab(2, k0 + 1, st2, rt2, dt2);
     write_vals(vs0);
     int vbcur = vb0;                // span begin of the plane whose values sit in LDS
     load_vals(vb1, vs1);
@@ -153,22 +210,22 @@ __global__ __launch_bounds__(T, 2) void spmv_vsweep_kernel(
     i2_t rp0 = load_rp(k0);
     if (aux) ax0 = load_pair(aux, k0);
     if (kExtra && extra) ex0 = load_pair(extra, k0);
-    load_slab(k0 + 2, st0);
+    load_slab(k0 + 2, st0, rt0, dt0);
     unsigned id1 = load_ids(k0 + 1);
     i2_t rp1 = load_rp(k0 + 1);
     if (aux) ax1 = load_pair(aux, k0 + 1);
     if (kExtra && extra) ex1 = load_pair(extra, k0 + 1);
-    load_slab(k0 + 3, st1);
+    load_slab(k0 + 3, st1, rt1, dt1);
     unsigned id2 = load_ids(k0 + 2);
     i2_t rp2 = load_rp(k0 + 2);
     if (aux) ax2 = load_pair(aux, k0 + 2);
     if (kExtra && extra) ex2 = load_pair(extra, k0 + 2);
-    load_slab(k0 + 4, st2);
+    load_slab(k0 + 4, st2, rt2, dt2);
     __syncthreads();
 
     // vbcur: span begin of plane k (its values are in sval now).  vsn / vbs: value stage of plane k+1 and its span begin,
     // re-loaded with plane k+4 whose span begin is vbn (fetched during the previous step).
-    auto step = [&](int k, d2_t(&st)[NL], unsigned &idr, i2_t &rpr, d2_t &axr, d2_t &exr, d2u_t(&vsn)[NVL], int &vbs) {
+    auto step = [&](int k, d2_t(&st)[NL], d2_t(&rt)[NLR], d2_t(&dt)[NLD], unsigned &idr, i2_t &rpr, d2_t &axr, d2_t &exr, d2u_t(&vsn)[NVL], int &vbs) {
       const int vbk = vbcur;
       const unsigned idc = idr;
       const i2_t rpc = rpr;
@@ -241,14 +298,14 @@ __global__ __launch_bounds__(T, 2) void spmv_vsweep_kernel(
       }
       __syncthreads();   // everybody has read this plane's values
       // slab k+2 (loaded three steps ago) into the slot plane k-2 occupied; the values of plane k+1 into the stage
-      write_slab((k - k0 + 3) & (NS - 1), st);
+      write_slab((k - k0 + 3) & (NS - 1), k + 2, st, rt, dt);
       write_vals(vsn);
       // look-ahead loads into the registers just consumed: ids / row pointers / aux of plane k+3, slab k+5, values k+4
       idr = load_ids(k + 3);
       rpr = load_rp(k + 3);
       if (aux) axr = load_pair(aux, k + 3);
       if (kExtra && extra) exr = load_pair(extra, k + 3);
-      load_slab(k + 5, st);
+      load_slab(k + 5, st, rt, dt);
       vbcur = vbs;
       vbs = vbn;
       load_vals(vbn, vsn);
@@ -256,9 +313,9 @@ __global__ __launch_bounds__(T, 2) void spmv_vsweep_kernel(
       __syncthreads();
     };
     for (int k = k0; k < k1; k += 3) {   // straight-line body: steps at or behind k1 compute nothing (live() is false)
-      step(k, st0, id0, rp0, ax0, ex0, vs1, vb1);
-      step(k + 1, st1, id1, rp1, ax1, ex1, vs2, vb2);
-      step(k + 2, st2, id2, rp2, ax2, ex2, vs0, vb0);
+      step(k, st0, rt0, dt0, id0, rp0, ax0, ex0, vs1, vb1);
+      step(k + 1, st1, rt1, dt1, id1, rp1, ax1, ex1, vs2, vb2);
+      step(k + 2, st2, rt2, dt2, id2, rp2, ax2, ex2, vs0, vb0);
     }
   }
   if (MODE != 0) {
@@ -267,16 +324,26 @@ __global__ __launch_bounds__(T, 2) void spmv_vsweep_kernel(
     block_sum<2, T>(w, ring);
     if (threadIdx.x == 0) {
       slab[0 * kSlabStride + blockIdx.x] = w[0];
-      if (MODE == 1) slab[1 * kSlabStride + blockIdx.x] = w[1];
+      if (MODE == 1 || MODE == 3) slab[1 * kSlabStride + blockIdx.x] = w[1];
     }
   }
 }
 
-template <int MODE, int NL, int NVL, int T>
+// CG arguments of MODE 3 (unused by the other modes)
+struct VsCg {
+  PcgState *st = nullptr;
+  const double *slab_in = nullptr;
+  int nblocks_in = 0, stride_in = kSlabStride;
+  double *pnew = nullptr;
+  int flags = 0;
+  double *norms = nullptr;
+};
+
+template <int MODE, int NL, int NVL, int T, bool PRE>
 static int launch_vsweep_t(const mk_matrix *A, const SweepArgs &S, size_t lds, int blocks, bool nt, double alpha, const double *x, double beta,
-                           double *y, double *slab, const int *done, const double *rhs, const double *extra) {
+                           double *y, double *slab, const int *done, const double *rhs, const double *extra, const VsCg &cg) {
   Context &c = ctx();
-  auto kern = nt ? spmv_vsweep_kernel<MODE, NL, NVL, T, true> : spmv_vsweep_kernel<MODE, NL, NVL, T, false>;
+  auto kern = nt ? spmv_vsweep_kernel<MODE, NL, NVL, T, true, PRE> : spmv_vsweep_kernel<MODE, NL, NVL, T, false, PRE>;
   // dynamic LDS above 48 KB needs an opt-in per kernel (no allocation).  The attribute belongs to the kernel, not to the
   // matrix: it is only ever raised, so a matrix with a smaller stage cannot lower it under one with a larger stage.
   static size_t lds_max[2] = {48 * 1024, 48 * 1024};   // per template instance and cache policy
@@ -285,14 +352,15 @@ static int launch_vsweep_t(const mk_matrix *A, const SweepArgs &S, size_t lds, i
     lds_max[nt ? 1 : 0] = lds;
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(T), lds, c.stream, S, A->etab, A->nrows, A->ncols, A->nnz, A->pat, A->pmask,
-                     A->npat, A->rowptr, A->val, x, y, alpha, beta, slab, done, rhs, extra);
+                     A->npat, A->rowptr, A->val, x, y, alpha, beta, slab, done, rhs, extra, cg.st, cg.slab_in, cg.nblocks_in,
+                     cg.stride_in, cg.pnew, cg.flags, cg.norms);
   MK_HIP(hipGetLastError());
   return MK_OK;
 }
 
-template <int MODE>
+template <int MODE, bool PRE = false>
 static int launch_vsweep_m(const mk_matrix *A, double alpha, const double *x, double beta, double *y, double *slab, const int *done,
-                           int *nblocks, const double *rhs, const double *extra) {
+                           int *nblocks, const double *rhs, const double *extra, const VsCg &cg = VsCg()) {
   Context &c = ctx();
   if (!A->sweep || !A->sweep_streamed || !A->pat)
     return fail(MK_ERR_UNSUPPORTED, "spmv: MK_SPMV_VSWEEP needs rows that are sub-lists, by column offset, of one grid pattern of at most 8 entries");
@@ -316,7 +384,7 @@ static int launch_vsweep_m(const mk_matrix *A, double alpha, const double *x, do
   if (dry_launch()) return MK_OK;
   const int nl = std::max(2, (S.sw + 2 * T - 1) / (2 * T));
   const bool nt = nt_rows(A->nrows) || nt_matrix((double)A->nnz * 8.0);
-#define MK_VS(NLL, NVV, TT) return launch_vsweep_t<MODE, NLL, NVV, TT>(A, S, lds, blocks, nt, alpha, x, beta, y, slab, done, rhs, extra);
+#define MK_VS(NLL, NVV, TT) return launch_vsweep_t<MODE, NLL, NVV, TT, PRE>(A, S, lds, blocks, nt, alpha, x, beta, y, slab, done, rhs, extra, cg);
 #define MK_VS_NV(NLL, TT)                \
   switch (nvl) {                         \
     case 3: MK_VS(NLL, 3, TT)            \
@@ -339,6 +407,18 @@ int launch_vsweep(const mk_matrix *A, int mode, double alpha, const double *x, d
   if (mode == 1) return launch_vsweep_m<1>(A, alpha, x, beta, y, slab, done, nblocks, rhs, extra);
   if (mode == 2) return launch_vsweep_m<2>(A, alpha, x, beta, y, slab, done, nblocks, rhs, extra);
   return fail(MK_ERR_INVALID, "launch_vsweep: mode %d", mode);
+}
+
+// CG step on vsweep matrices, first kernel from the second iteration on: p_new = z + beta p_old formed in the window fill
+// (z = r, or r * dinv per row), s = A p_new, partials of <s, p_new>, <p_new, p_new> into slab_out; prologue = K3's
+int launch_vsweep_cg_pdots(const mk_matrix *A, const double *r, const double *p_old, double *p_new, const double *dinv, double *s,
+                           const double *slab_in, int nblocks_in, int stride_in, double *slab_out, PcgState *st, int two_norm,
+                           int rel_change, double *norms, int *nblocks) {
+  VsCg cg;
+  cg.st = st; cg.slab_in = slab_in; cg.nblocks_in = nblocks_in; cg.stride_in = stride_in; cg.pnew = p_new;
+  cg.flags = (two_norm ? 1 : 0) | (rel_change ? 2 : 0); cg.norms = norms;
+  if (dinv) return launch_vsweep_m<3, true>(A, 1.0, p_old, 0.0, s, slab_out, nullptr, nblocks, r, dinv, cg);
+  return launch_vsweep_m<3, false>(A, 1.0, p_old, 0.0, s, slab_out, nullptr, nblocks, r, nullptr, cg);
 }
 
 }  // namespace mk

@@ -407,6 +407,57 @@ def test_spmv_vsweep_kernel_variable_coefficients(kind, dims):
     assert np.allclose(hist[:m], o["rel_norms"][:m], rtol=1e-8)
 
 
+@pytest.mark.parametrize("kind,dims", [(7, (64, 64, 40)), (7, (30, 22, 10)), (5, (128, 96, 1)), (7, (640, 4, 6)), (7, (1024, 3, 9)), (7, (6, 6, 100))])
+@pytest.mark.parametrize("precond", [0, 1])
+@pytest.mark.parametrize("rel_change", [0, 1])
+def test_pcg_vsweep_fused_k3_matches_oracle(kind, dims, precond, rel_change):
+    """CG on variable-coefficient grids: from the second iteration on K3 rides in the window fill of the
+    vsweep product (p' = z + beta p formed while the window is loaded, own rows to the other p buffer, with the Jacobi
+    preconditioner 1/diag as a third window stream), K2 unchanged.  Same recurrences and stopping rule as the three-kernel
+    loop: iteration counts, residual history, exact-k solutions and the zero right-hand side against orc_pcg (parity
+    unpinned: hypre itself is not available)."""
+    rp, ci, v = oracle.stencil_csr(kind, *dims, scale_seed=23)
+    n = rp.size - 1
+    tol = 1e-9
+    bh = np.random.default_rng(n).normal(size=n)
+    o = oracle.pcg(rp, ci, v, bh, tol=tol, precond=precond, maxit=600, want_norms=True, rel_change=rel_change)
+    A = mk.Matrix.from_csr(n, n, rp, ci, v)
+    A.set_spmv_kernel(mk.SPMV_VSWEEP)
+    for check_every in (1, 7):
+        b, x = mk.Vector(n, values=bh), mk.Vector(n, fill=0.0)
+        S = mk.PCG(max_iter=600, tol=tol, two_norm=1, rel_change=rel_change, precond=precond, logging=1, check_every=check_every)
+        S.setup(A, b, x)
+        res = S.solve(A, b, x)
+        assert res["converged"] == o["converged"]
+        assert abs(res["iterations"] - o["iterations"]) <= CG_ITER_TOL, (res, o["iterations"])
+        xs = x.get()
+        assert np.linalg.norm(xs - o["x"]) <= 1e-6 * np.linalg.norm(o["x"])
+        hist = S.residual_history(2000)
+        assert hist.size == res["iterations"] + 1
+        m = min(hist.size, o["rel_norms"].size, 40)
+        assert np.allclose(hist[:m], o["rel_norms"][:m], rtol=1e-8)
+        if res["converged"]:
+            assert res["rel_res_norm"] < tol
+            assert np.linalg.norm(bh - oracle.csr_spmv(rp, ci, v, xs)) / np.linalg.norm(bh) < tol * 1.5
+    for k in (1, 2, 3, 6):      # exactly k iterations; p ping-pongs between two buffers from the second one on
+        b, x = mk.Vector(n, values=bh), mk.Vector(n, fill=0.0)
+        S = mk.PCG(max_iter=k, tol=1e-30, rel_change=rel_change, precond=precond)
+        S.setup(A, b, x)
+        res = S.solve(A, b, x)
+        ok = oracle.pcg(rp, ci, v, bh, tol=1e-30, precond=precond, maxit=k, rel_change=rel_change)
+        assert res["iterations"] == k and res["converged"] == 0
+        assert np.isclose(res["rel_res_norm"], ok["rel_res_norm"], rtol=1e-9)
+        assert np.allclose(x.get(), ok["x"], rtol=1e-9, atol=1e-13)
+        if k == 6:              # a second solve on the same solver object starts from the previous x (solvers.c:753-754)
+            res2 = S.solve(A, b, x)
+            ok2 = oracle.pcg(rp, ci, v, bh, x0=ok["x"], tol=1e-30, precond=precond, maxit=k, rel_change=rel_change)
+            assert res2["iterations"] == k and np.allclose(x.get(), ok2["x"], rtol=1e-8, atol=1e-12)
+    b0, x0 = mk.Vector(n, fill=0.0), mk.Vector(n, fill=3.0)
+    S = mk.PCG(max_iter=10, tol=1e-9, precond=precond, rel_change=rel_change)
+    S.setup(A, b0, x0)
+    assert S.solve(A, b0, x0)["iterations"] == 0 and np.all(x0.get() == 0.0)
+
+
 def test_spmv_vsweep_device_generated_matches_oracle_generator():
     """mk_matrix_generate_stencil_scaled and the oracle's restatement of it give the same bits; 192 x 160 x 72 is large
     enough for the selector to take the vsweep kernel by itself"""
