@@ -125,6 +125,10 @@ typedef struct {
   int32_t stream_chunk;    /* ... and the entries of its fullest chunk (what the kernel stages in LDS) */
   int64_t shared_columns;  /* > 0: that many entries sit in rows that repeat the column list of the row before them (several
                               unknowns per mesh node); MK_SPMV_STREAM reads such a list once (lossless, same order) */
+  int64_t row_groups;      /* > 0: MK_SPMV_STREAM serves the product group by group (runs of up to 4 consecutive rows with one
+                              column list): x is gathered once per list and multiplied with every row of the group */
+  int32_t group_lanes;     /* ... with this many lanes per group */
+  int32_t reserved0;
 } mk_matrix_info;
 int mk_matrix_get_info(const mk_matrix *A, mk_matrix_info *info);
 

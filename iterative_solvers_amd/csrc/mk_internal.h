@@ -157,6 +157,12 @@ struct mk_matrix {
   int *colc = nullptr;             // stream kernel, rows that repeat the column list of the row before them (the unknowns of one mesh node):
   int *cptr = nullptr;             // colc = the lists stored once, cptr[row] = where row's list starts in colc
   int64_t colc_len = 0;
+  // row-group kernel (group.hip): runs of up to 4 consecutive rows with one column list; grow[g] = first row of group g
+  // (ngroups + 1 entries), gcol[g] = start of its list in colc
+  int *grow = nullptr, *gcol = nullptr;
+  int *gdesc = nullptr, *cdesc = nullptr;   // 16 bytes per group / per chunk: what a lane / a block loads of them (group.hip)
+  int ngroups = 0, group_lanes = 0, group_cap = 0, group_ccap = 0, group_chunks = 0;
+  mutable int group_bpc[2] = {0, 0};
   double *vtab = nullptr;          // npat x pml doubles when the rows of a pattern also share their values
                                    // (pattern kernel: neither col[] nor val[] nor rowptr[] is read)
   int *otab8 = nullptr;            // pattern kernel's padded copies of ptab / vtab (row stride p8 + 8 ints, p8 doubles)
@@ -237,6 +243,10 @@ int launch_vsweep(const mk_matrix *A, int mode, double alpha, const double *x, d
 int launch_vsweep_cg_pdots(const mk_matrix *A, const double *r, const double *p_old, double *p_new, const double *dinv, double *s,
                            const double *slab_in, int nblocks_in, int stride_in, double *slab_out, PcgState *st, int two_norm,
                            int rel_change, double *norms, int *nblocks);
+
+// rows that repeat their neighbour's column list: groups of such rows, served by spmv_group_kernel (group.hip)
+int build_row_groups(mk_matrix *A);
+int launch_group(const mk_matrix *A, int mode, double alpha, const double *x, double beta, double *y, double *slab, const int *done, int *nblocks);
 
 int exclusive_scan_u32(const uint32_t *in, uint32_t *out, size_t n, uint32_t *total_out_dev);
 

@@ -629,6 +629,7 @@ int analyse_matrix(mk_matrix *A) {
     MK_TRY(try_compress<true>(A));                 // offsets and values shared by rows -> pattern kernel
     if (!A->pat) MK_TRY(try_compress<false>(A));   // offsets only -> stream kernel without col[]
     if (!A->pat) MK_TRY(try_share_columns(A));     // rows repeating their neighbour's column list -> lists stored once
+    if (!A->pat && A->cptr) MK_TRY(build_row_groups(A));   // ... and x gathered once per list (row-group kernel)
     if (A->vtab && was_auto) A->kernel = (A->sweep && A->sweep_auto) ? MK_SPMV_SWEEP : MK_SPMV_PATTERN;
     static const int no_vsweep = getenv("MK_NO_VSWEEP") ? atoi(getenv("MK_NO_VSWEEP")) : 0;
     if (!A->vtab && A->pat && A->sweep && A->sweep_streamed && A->sweep_auto && was_auto && !no_vsweep) A->kernel = MK_SPMV_VSWEEP;
@@ -637,6 +638,8 @@ int analyse_matrix(mk_matrix *A) {
   I.index_patterns = A->pat ? A->npat : 0;
   I.value_patterns = A->vtab ? A->npat : 0;
   I.shared_columns = A->cptr ? A->nnz - A->colc_len : 0;
+  I.row_groups = A->grow ? A->ngroups : 0;
+  I.group_lanes = A->grow ? A->group_lanes : 0;
   A->analysed = true;
   return MK_OK;
 }
@@ -2082,6 +2085,7 @@ int launch_spmv(const mk_matrix *A, double alpha, const double *x, double beta, 
   if (A->kernel == MK_SPMV_VSWEEP) return launch_vsweep(A, 0, alpha, x, beta, y, nullptr, skip, nullptr, nullptr, nullptr);
   if (A->kernel == MK_SPMV_SWEEP) return launch_sweep<0>(A, alpha, x, beta, y, nullptr, skip, nullptr);
   if (A->kernel == MK_SPMV_PATTERN) return launch_pattern<0>(A, alpha, x, beta, y, nullptr, skip, nullptr);
+  if (A->kernel == MK_SPMV_STREAM && A->grow) return launch_group(A, 0, alpha, x, beta, y, nullptr, skip, nullptr);
   if (A->kernel == MK_SPMV_STREAM) return launch_stream<0>(A, alpha, x, beta, y, nullptr, skip, nullptr);
   if (A->kernel == MK_SPMV_SPLIT) return launch_split<0>(A, alpha, x, beta, y, nullptr, skip, nullptr);
   return launch_vector<0>(A, alpha, x, beta, y, nullptr, skip, nullptr);
@@ -2152,6 +2156,7 @@ int launch_spmv_dot(const mk_matrix *A, const double *x, double *y, double *slab
   if (A->kernel == MK_SPMV_VSWEEP) return launch_vsweep(A, 1, 1.0, x, 0.0, y, slab, done, nblocks, nullptr, nullptr);
   if (A->kernel == MK_SPMV_SWEEP) return launch_sweep<1>(A, 1.0, x, 0.0, y, slab, done, nblocks);
   if (A->kernel == MK_SPMV_PATTERN) return launch_pattern<1>(A, 1.0, x, 0.0, y, slab, done, nblocks);
+  if (A->kernel == MK_SPMV_STREAM && A->grow) return launch_group(A, 1, 1.0, x, 0.0, y, slab, done, nblocks);
   if (A->kernel == MK_SPMV_STREAM) return launch_stream<1>(A, 1.0, x, 0.0, y, slab, done, nblocks);
   if (A->kernel == MK_SPMV_SPLIT) return launch_split<1>(A, 1.0, x, 0.0, y, slab, done, nblocks);
   return launch_vector<1>(A, 1.0, x, 0.0, y, slab, done, nblocks);

@@ -859,6 +859,106 @@ def test_spmv_shared_column_lists_mixtures(seed, n, p_same, p_empty):
         assert np.allclose(xs.get(), o["x"], rtol=1e-12, atol=0)
 
 
+def _grouped_matrix(rng, nodes, run_lens, list_len, window):
+    """rows in runs that share one column list each (run lengths drawn from run_lens), lists of about list_len columns in
+    blocks of three within +-window nodes, every entry its own value"""
+    lists, lens = [], []
+    node = 0
+    while node < nodes:
+        k = int(rng.choice(run_lens))
+        m = max(1, int(rng.integers(max(1, list_len // 2), list_len * 3 // 2 + 1)) // 3)
+        nb = np.unique(np.concatenate([[node], rng.integers(max(0, node - window), min(nodes, node + window + 1), m)]))
+        lst = (np.repeat(nb * 3, 3) + np.tile(np.arange(3), nb.size)).astype(np.int64)
+        for _ in range(k):
+            lists.append(lst)
+        node += 1
+    n = len(lists)
+    ncols = 3 * nodes
+    lens = np.array([l.size for l in lists])
+    rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    ci = np.concatenate(lists).astype(np.int32)
+    v = rng.normal(size=ci.size)
+    return n, ncols, rp, ci, v
+
+
+@pytest.mark.parametrize("seed,nodes,run_lens,list_len,window", [
+    (1, 3000, [3], 78, 300),                      # three unknowns per node: the shape of the authors' finite-element inputs
+    (2, 2500, [1, 2, 3, 4, 5, 9], 40, 200),       # runs longer than a group (cut every four rows) among single rows
+    (3, 1200, [3, 6], 200, 900),                  # lists beyond eight entries per lane (the batches of four)
+    (4, 4000, [2, 3], 12, 50),                    # short lists, many groups per chunk
+    (5, 700, [64], 30, 100),                      # long runs: most groups are continuations of the run before them
+])
+def test_spmv_row_group_kernel(seed, nodes, run_lens, list_len, window):
+    """matrices whose consecutive rows repeat one column list are multiplied group by group (group.hip):
+    x gathered once per list, one multiply-add per row of the group.  Product (alpha / beta forms), product + dots and the
+    untouched CSR arrays against the oracle on the CSR as given, 1e-12 per row."""
+    rng = np.random.default_rng(seed)
+    n, ncols, rp, ci, v = _grouped_matrix(rng, nodes, run_lens, list_len, window)
+    A = mk.Matrix.from_csr(n, ncols, rp, ci, v)
+    i = A.info()
+    assert i.kernel == mk.SPMV_STREAM and i.index_patterns == 0 and i.shared_columns > 0
+    assert i.row_groups > 0 and i.group_lanes >= 4, (i.row_groups, i.group_lanes)
+    # groups: every run of k rows gives ceil(k / 4) of them
+    same = np.zeros(n, bool)
+    for r in range(1, n):
+        same[r] = rp[r + 1] - rp[r] == rp[r] - rp[r - 1] and np.array_equal(ci[rp[r - 1]:rp[r]], ci[rp[r]:rp[r + 1]])
+    starts = np.flatnonzero(~same)
+    runs = np.diff(np.concatenate([starts, [n]]))
+    assert i.row_groups == int(np.sum((runs + 3) // 4))
+    _check_spmv(A, rp, ci, v, n, ncols, rng)
+    _check_spmv(A, rp, ci, v, n, ncols, rng, alpha=-0.75, beta=1.25)
+    _check_spmv(A, rp, ci, v, n, ncols, rng, alpha=2.0, beta=-1.0)
+    rp_b, ci_b, v_b = A.to_csr()
+    assert np.array_equal(rp_b, rp) and np.array_equal(ci_b, ci) and _same_bits(v_b, v)
+    if n == ncols:
+        xh = rng.normal(size=n)
+        x, y = mk.Vector(n, values=xh), mk.Vector(n, fill=5.0)
+        yx, xx = A.spmv_dot(x, y)
+        ref = oracle.csr_spmv(rp, ci, v, xh)
+        mag = oracle.csr_spmv(rp, ci, np.abs(v), np.abs(xh))
+        assert (np.abs(y.get() - ref) / np.maximum(mag, 1e-300)).max() <= SPMV_RTOL
+        assert abs(yx - ref @ xh) <= 1e-12 * np.abs(ref * xh).sum() and abs(xx - xh @ xh) <= 1e-12 * (xh @ xh)
+
+
+def test_pcg_on_a_three_unknowns_per_node_matrix_through_the_row_group_kernel():
+    """CG (solver id 50 and 51) on a symmetric positive definite matrix with 3 x 3 node blocks: K1 runs on the row-group kernel;
+    iteration count, history and solution against orc_pcg"""
+    rng = np.random.default_rng(11)
+    nodes = 2000
+    nb = [np.unique(np.concatenate([[i], rng.integers(max(0, i - 60), min(nodes, i + 61), 9)])) for i in range(nodes)]
+    adj = np.zeros((0, 2), np.int64)
+    pairs = np.concatenate([np.stack([np.full(q.size, i), q], 1) for i, q in enumerate(nb)])
+    pairs = np.unique(np.concatenate([pairs, pairs[:, ::-1]]), axis=0)                 # symmetric node graph, sorted by (row, col)
+    r3 = (pairs[:, 0, None, None] * 3 + np.arange(3)[None, :, None] + np.zeros((1, 1, 3), np.int64)).reshape(-1)
+    c3 = (pairs[:, 1, None, None] * 3 + np.arange(3)[None, None, :] + np.zeros((1, 3, 1), np.int64)).reshape(-1)
+    order = np.lexsort((c3, r3))
+    r3, c3 = r3[order], c3[order]
+    n = 3 * nodes
+    w = rng.uniform(-1.0, 1.0, r3.size)
+    lo, hi = np.minimum(r3, c3), np.maximum(r3, c3)
+    key = lo * n + hi
+    _, inv = np.unique(key, return_inverse=True)
+    w = rng.uniform(-1.0, 1.0, inv.max() + 1)[inv]                                     # symmetric values
+    absum = np.bincount(r3, weights=np.abs(w), minlength=n)
+    w[r3 == c3] = 1.2 * absum[r3[r3 == c3]] + 1.0                                      # strictly dominant diagonal: SPD
+    rp = np.concatenate([[0], np.cumsum(np.bincount(r3, minlength=n))]).astype(np.int32)
+    ci = c3.astype(np.int32)
+    A = mk.Matrix.from_csr(n, n, rp, ci, w)
+    assert A.info().row_groups > 0
+    bh = rng.normal(size=n)
+    for precond in (0, 1):
+        o = oracle.pcg(rp, ci, w, bh, tol=1e-10, precond=precond, maxit=500, want_norms=True)
+        b, x = mk.Vector(n, values=bh), mk.Vector(n, fill=0.0)
+        S = mk.PCG(max_iter=500, tol=1e-10, two_norm=1, rel_change=1, precond=precond, logging=1)
+        S.setup(A, b, x)
+        res = S.solve(A, b, x)
+        assert res["converged"] == 1 == o["converged"] and abs(res["iterations"] - o["iterations"]) <= CG_ITER_TOL
+        assert np.linalg.norm(x.get() - o["x"]) <= 1e-8 * np.linalg.norm(o["x"])
+        hist = S.residual_history(1000)
+        m = min(hist.size, o["rel_norms"].size, 30)
+        assert np.allclose(hist[:m], o["rel_norms"][:m], rtol=1e-8)
+
+
 @pytest.mark.parametrize("dof,nx,ny", [(2, 37, 23), (4, 20, 31)])
 def test_spmv_pattern_shapes_short_rows(dof, nx, ny):
     """several unknowns per node of a 2-D 5-point grid, every entry its own value: the index patterns of a node's rows differ
