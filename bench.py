@@ -368,6 +368,7 @@ def main():
         traffic_db = json.load(open(tpath))
 
     solve_times = {}
+    spmv_only = {}
 
     def measure(name, steps, warmup, timing=True):
         """CG on workload `name`: a warm-up solve, the timed solve (wall clock around mk_pcg_solve, stream drained on
@@ -399,6 +400,17 @@ def main():
         dt, res, _ = runs[len(runs) // 2]
         solve_times[name] = [round(t[0] * 1e3 / steps, 4) for t in runs]
         kt = run(34, True)[2] if timing else None
+        if timing and A.info().kernel == 6:
+            # the plain product + dots of the same operator (mk_spmv_dot: MODE 1 of the kernel, the first step's K1), 20 launches
+            # between two HIP events on the library's stream
+            xs, ys = mk.Vector(n, fill=1.0), mk.Vector(n)
+            for _ in range(3):
+                A.spmv_dot(xs, ys, want=False)
+            mk.timer_start()
+            for _ in range(20):
+                A.spmv_dot(xs, ys, want=False)
+            spmv_only[name] = mk.timer_stop() / 20
+            del xs, ys
         return A, dt, res, kt
 
     def kernel_blocks(name, A, kt):
@@ -416,6 +428,21 @@ def main():
                      ("spmv_sweep_kernel MODE 4 (r -= alpha A p recomputed, x += alpha p, dots)", 42 * n, "42 B/row: 2 B pattern id, p 8, r 8 + 8, x 8 + 8")]
             if kt is not None and len(kt) == 3:
                 slots.append(("pcg_update_p_kernel (K3)", 24 * n, "24 B/row"))
+        elif info.kernel == 6 and kt is not None and len(kt) == 2 and not os.environ.get("MK_NO_FUSED_K3"):
+            # variable-coefficient grids: K3 (p' = z + beta p) and the solution update ride in the window fill of
+            # the product; K2 streams s and r only.  Bytes by SURVEY 8(d)'s own accounting of the passes each kernel carries:
+            # SpMV 12 nnz + 20 n + 4, direction pass 24 n, update pass 48 n.
+            defx = not os.environ.get("MK_NO_DEFERRED_X") and not precond
+            k1b = csr + 24 * n + (24 * n if defx else 0) + (8 * n if precond else 0)
+            k2b = ((24 if defx else 48) + (8 if precond else 0)) * n
+            slots = [("spmv_vsweep_kernel MODE 3 (K1 + K3" + (" + x update" if defx else "") + ": p' = z + beta p in the window fill, s = A p', <s,p'>, <p',p'>"
+                      + (", x += alpha p_old" if defx else "") + ")", k1b,
+                      "SURVEY 8(d): SpMV 12 nnz + 20 n + 4, direction pass 24 n" + (", the x half of the update pass (x read + write, p read) 24 n" if defx else "")
+                      + (", 1/diag 8 n" if precond else "") + f"; the kernel itself moves 8 nnz + {36 + (16 if defx else 0) + (8 if precond else 0)} n "
+                      "(no col[], p' and p_old read once)"),
+                     ("pcg_update_r_kernel (K2 without x: r -= alpha s, <r,z>, <r,r>)" if defx else "pcg_update_xr_kernel (K2)", k2b,
+                      "SURVEY 8(d): the r half of the update pass (r read + write, s read) 24 n" + (", 1/diag 8 n" if precond else "") if defx
+                      else "x, r read+write, p, s read" + (", 1/diag" if precond else ""))]
         else:
             own = csr if info.kernel in (1, 2, 3, 6) else 18 * n + 4
             slots = [(f"spmv+dot, {kname} kernel (K1: s = A p, <s,p>, <p,p>)", own,
@@ -484,13 +511,18 @@ def main():
         out["roofline"] = {
             "bound": "hbm", "workload": WORKLOADS[vname][6], "name": vname,
             "kernel": k1["kernel"] + " -- the dominant kernel of the CG loop on this operator; reads val[] (8 B/entry), "
-                      "a 2-byte column-pattern id per row in place of col[] (lossless), row pointers, x; writes y",
+                      "a 2-byte column-pattern id per row in place of col[] (lossless), 2 B of row pointer per row",
             "achieved": k1["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": k1["frac"],
-            "bytes_per_launch": vcsr, "bytes_model": "SURVEY 8(d): 12 nnz + 20 n + 4 (values + column indices + row pointers + x/y)",
+            "bytes_per_launch": k1["bytes_per_launch"], "bytes_model": k1["bytes_model"],
             "avg_launch_ms": k1["avg_launch_ms"], "launches_timed": k1["launches_timed"],
             "measured": "HIP events around the kernel inside mk_pcg_solve, on the library's stream",
             "traffic": k1["traffic"], "traffic_frac": k1["traffic_frac"],
             "target_0_75_met": bool(k1["frac"] is not None and k1["frac"] >= 0.75),
+            "spmv_only": None if vname not in spmv_only else {
+                "kernel": "spmv_vsweep_kernel MODE 1: the plain product + dots of the same operator (what the loop's first step runs)",
+                "avg_launch_ms": round(spmv_only[vname], 5), "launches_timed": 20, "bytes_per_launch": vcsr,
+                "achieved": round(vcsr / (spmv_only[vname] * 1e-3) / 1e9, 1), "frac": round(vcsr / (spmv_only[vname] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "traffic": traffic_db.get(f"{vname}:spmv_only")},
             "index_patterns": vinfo.index_patterns, "value_patterns": vinfo.value_patterns,
             "cg": {"value": round(args.steps / vdt, 2), "unit": "CG iterations/s", "ms_per_step": round(vms, 4),
                    "iteration_bytes": viter, "iteration_GBps": round(viter / (vms * 1e-3) / 1e9, 1),

@@ -312,7 +312,7 @@ static int grid1(int64_t n, int cap = 4096) { return (int)std::max<int64_t>(1, s
 
 static void release_dist(mk_dist_matrix *D) {
   auto freem = [](mk_matrix &M) {
-    dev_free(M.rowptr); dev_free(M.col); dev_free(M.val); dev_free(M.dinv); dev_free(M.chunk_row); dev_free(M.long_rows); dev_free(M.carry); dev_free(M.pat); dev_free(M.ptab); dev_free(M.stab); dev_free(M.colc); dev_free(M.cptr); dev_free(M.grow); dev_free(M.gcol); dev_free(M.gdesc); dev_free(M.cdesc); dev_free(M.vtab); dev_free(M.otab8); dev_free(M.vtab8); dev_free(M.pmask); dev_free(M.etab); dev_free(M.sweep_perm); delete M.sweep;
+    dev_free(M.rowptr); dev_free(M.col); dev_free(M.val); dev_free(M.dinv); dev_free(M.chunk_row); dev_free(M.long_rows); dev_free(M.carry); dev_free(M.pat); dev_free(M.ptab); dev_free(M.stab); dev_free(M.colc); dev_free(M.cptr); dev_free(M.rowpair); dev_free(M.grow); dev_free(M.gcol); dev_free(M.gdesc); dev_free(M.cdesc); dev_free(M.vtab); dev_free(M.otab8); dev_free(M.vtab8); dev_free(M.pmask); dev_free(M.etab); dev_free(M.sweep_perm); delete M.sweep;
     dev_free(M.col2); dev_free(M.xg); dev_free(M.xorder);
     M = mk_matrix();
   };

@@ -148,6 +148,12 @@ int mk_pcg_solve(mk_pcg *S, const mk_matrix *A, const mk_vector *b, mk_vector *x
   // 12 nnz + 86 n bytes of the CSR model's 12 nnz + 92 n, and one launch less.
   const bool vfuse = (A->kernel == MK_SPMV_VSWEEP) && !no_fused && !no_pfuse && S->p2 != nullptr;
   if (vfuse) palt = S->p2;
+  // ... and the solution update rides there as well, one kernel late (x += alpha p while the fill has p in registers):
+  // K2 then streams s and r only.  12 nnz + 78 n bytes.  The update of the last completed step is applied after the loop.
+  static const int no_defx = getenv("MK_NO_DEFERRED_X") ? atoi(getenv("MK_NO_DEFERRED_X")) : 0;
+  // (not with the Jacobi preconditioner: its 1/diag is a third window stream already and the kernel runs out of registers:
+  // 256^3 0.511 -> 0.535 ms per iteration; without a preconditioner 512^3 3.58 -> 3.32 ms, 256^3 0.436 -> 0.434)
+  const bool defx = vfuse && !no_defx && !dinv;
   int nb2 = 0;
   // kernel timing: an event in front of every kernel of iterations 1 .. kTimedIters (the first iteration runs another
   // first kernel on the fused path) and one behind the last of them
@@ -183,13 +189,19 @@ int mk_pcg_solve(mk_pcg *S, const mk_matrix *A, const mk_vector *b, mk_vector *x
     } else if (vfuse) {
       if (it > 0) {
         MK_TRY(launch_vsweep_cg_pdots(A, S->r, pcur, palt, dinv, S->s, S->slab2, vb, kSlabStride, S->slab1, S->state, S->two_norm,
-                                      S->rel_change, S->norms, &nb1));
+                                      S->rel_change, S->norms, &nb1, defx ? x->d : nullptr));
         std::swap(pcur, palt);
       } else {
         MK_TRY(launch_spmv_dot(A, pcur, S->s, S->slab1, &S->state->done, &nb1));
       }
       stamp(it);
-      if (dinv)
+      if (defx && it > 0) {   // (the first step's product ran without a fill: its K2 updates x itself)
+        const int pb = (pcur == S->p2) ? 1 : 0;
+        if (dinv)
+          hipLaunchKernelGGL((pcg_update_r_kernel<true>), dim3(vb), dim3(kVecThreads), 0, c.stream, n, S->s, dinv, S->r, S->slab1, nb1, kSlabStride, S->slab2, S->state, pb, vec_flags(n));
+        else
+          hipLaunchKernelGGL((pcg_update_r_kernel<false>), dim3(vb), dim3(kVecThreads), 0, c.stream, n, S->s, dinv, S->r, S->slab1, nb1, kSlabStride, S->slab2, S->state, pb, vec_flags(n));
+      } else if (dinv)
         hipLaunchKernelGGL((pcg_update_xr_kernel<true>), dim3(vb), dim3(kVecThreads), 0, c.stream, n, pcur, S->s, dinv, x->d, S->r, S->slab1, nb1, kSlabStride, S->slab2, S->state, vec_flags(n));
       else
         hipLaunchKernelGGL((pcg_update_xr_kernel<false>), dim3(vb), dim3(kVecThreads), 0, c.stream, n, pcur, S->s, dinv, x->d, S->r, S->slab1, nb1, kSlabStride, S->slab2, S->state, vec_flags(n));
@@ -223,6 +235,10 @@ int mk_pcg_solve(mk_pcg *S, const mk_matrix *A, const mk_vector *b, mk_vector *x
     }
   }
   if (tev_used > 0 && tev_used == timed_iters * nslots) (void)hipEventRecord(S->tev[tev_used++], c.stream);   // solve ended with the timed window
+  if (defx && S->max_iter > 1) {   // the solution update of the last completed step, if it is still pending
+    hipLaunchKernelGGL(pcg_apply_pending_x_kernel, dim3(vb), dim3(kVecThreads), 0, c.stream, n, x->d, S->p, S->p2, S->state);
+    hipLaunchKernelGGL(pcg_clear_pending_kernel, dim3(1), dim3(1), 0, c.stream, S->state);
+  }
   if ((fuse_p || vfuse) && S->max_iter > 0)   // the test that the next step's first kernel would have made (K3's prologue; n = 0: no p update)
     hipLaunchKernelGGL((pcg_update_p_kernel<false>), dim3(1), dim3(kVecThreads), 0, c.stream, (int64_t)0, S->r, (const double *)nullptr, pcur, S->slab2, nb2, kSlabStride, S->two_norm, S->rel_change, S->state, S->norms, 0);
   MK_HIP(hipGetLastError());

@@ -158,6 +158,76 @@ __global__ __launch_bounds__(kVecThreads) void pcg_update_xr_kernel(int64_t n, c
   if (leader) { st->alpha = alpha; st->gamma_old = gamma; st->pp = pp; st->sdotp = sdotp; st->iter += 1; }
 }
 
+// K2 of the CG loop with the deferred solution update (vsweep matrices): r -= alpha s only.  x += alpha p is left pending
+// (state record: x_pending, pbuf) for the window fill of the next product, which has p in registers anyway; <x,x> after
+// that update follows from the partials the product kernel left: <x,x> + 2 alpha <x,p> + alpha^2 <p,p>.  slab_in: 4 components
+// (<s,p>, <p,p>, <x,x>, <x,p>); slab_out as K2's (<r,z>, <r,r>, <x,x> in block 0's slot).
+template <bool PRECOND>
+__global__ __launch_bounds__(kVecThreads) void pcg_update_r_kernel(int64_t n, const double *__restrict__ s, const double *__restrict__ dinv,
+                                                                   double *__restrict__ r, const double *__restrict__ slab_in, int nblocks_in,
+                                                                   int stride_in, double *__restrict__ slab_out, PcgState *st, int pbuf, int nt) {
+  if (block_flag_raised(&st->done)) return;
+  __shared__ double smem[4 * (kVecThreads / 64)];
+  double d[4];
+  reduce_slab<4, kVecThreads>(slab_in, nblocks_in, stride_in, d, smem);
+  const double sdotp = d[0], pp = d[1];
+  const double gamma = st->gamma;
+  const bool leader = (blockIdx.x == 0 && threadIdx.x == 0);
+  if (sdotp == 0.0) {
+    if (leader) { st->iter += 1; st->breakdown = 1; st->done = 2; st->x_pending = 0; }
+    return;
+  }
+  const double alpha = gamma / sdotp;
+  if (!(alpha > DBL_MIN)) {
+    if (leader) { st->iter += 1; st->breakdown = 2; st->done = 2; st->x_pending = 0; }
+    return;
+  }
+  double v[3] = {0.0, 0.0, 0.0};
+  const int64_t n2 = n >> 1;
+  const double2 *s2 = reinterpret_cast<const double2 *>(s);
+  const double2 *d2 = reinterpret_cast<const double2 *>(dinv);
+  double2 *r2 = reinterpret_cast<double2 *>(r);
+  auto rows = [&](auto tag) {
+  constexpr bool NT = decltype(tag)::value;
+  vec_rows(n2, nt >> 1, [&](int64_t i) {
+    const double2 sv = MK_VEC_LD(s2 + i);
+    double2 rv = MK_VEC_LD(r2 + i);
+    rv.x -= alpha * sv.x; rv.y -= alpha * sv.y;
+    MK_VEC_ST(r2 + i, rv);
+    double zx = rv.x, zy = rv.y;
+    if (PRECOND) { const double2 dv = MK_VEC_LD(d2 + i); zx *= dv.x; zy *= dv.y; }
+    v[0] += rv.x * zx + rv.y * zy;
+    v[1] += rv.x * rv.x + rv.y * rv.y;
+  });
+  };
+  if (nt & 1) rows(std::true_type{}); else rows(std::false_type{});
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const int64_t i = n - 1;
+    const double ri = r[i] - alpha * s[i];
+    r[i] = ri;
+    const double zi = PRECOND ? ri * dinv[i] : ri;
+    v[0] += ri * zi; v[1] += ri * ri;
+  }
+  block_sum<3, kVecThreads>(v, smem);
+  if (threadIdx.x == 0) {
+    slab_out[0 * kSlabStride + blockIdx.x] = v[0];
+    slab_out[1 * kSlabStride + blockIdx.x] = v[1];
+    // <x,x> once the pending update is in: one number, carried in block 0's slot (the others add zero)
+    slab_out[2 * kSlabStride + blockIdx.x] = (blockIdx.x == 0) ? d[2] + 2.0 * alpha * d[3] + alpha * alpha * pp : 0.0;
+  }
+  if (leader) { st->alpha = alpha; st->gamma_old = gamma; st->pp = pp; st->sdotp = sdotp; st->iter += 1; st->x_pending = 1; st->pbuf = pbuf; }
+}
+
+// the pending solution update of the last completed step (see above), applied after the loop; p0 / p1: the two p buffers
+static __global__ __launch_bounds__(kVecThreads) void pcg_apply_pending_x_kernel(int64_t n, double *__restrict__ x, const double *__restrict__ p0,
+                                                                                 const double *__restrict__ p1, const PcgState *st) {
+  if (st->x_pending == 0) return;
+  const double alpha = st->alpha;
+  const double *p = st->pbuf ? p1 : p0;
+  for (int64_t i = (int64_t)blockIdx.x * kVecThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kVecThreads) x[i] += alpha * p[i];
+}
+static __global__ void pcg_clear_pending_kernel(PcgState *st) { st->x_pending = 0; }
+
 // K3
 template <bool PRECOND>
 __global__ __launch_bounds__(kVecThreads) void pcg_update_p_kernel(int64_t n, const double *__restrict__ r,

@@ -106,6 +106,8 @@ struct PcgState {
   int done;        // 0 running, 1 converged, 2 breakdown
   int converged;
   int breakdown;   // 1 zero <s,p>, 2 subnormal alpha, 3 subnormal gamma
+  int x_pending;   // deferred solution update (vsweep CG): x += alpha p of the last completed step has not been applied yet
+  int pbuf;        // ... and which of the two p buffers that p is in
   int pad;
 };
 
@@ -172,6 +174,7 @@ struct mk_matrix {
   unsigned *pmask = nullptr;       // device, npat: which entries of the base pattern each pattern keeps
   mk::SweepEntry *etab = nullptr;  // device, 32 entries
   bool sweep_auto = false;         // enough parallelism for the sweep kernel to be the default
+  int *rowpair = nullptr;          // vsweep kernel: rowptr[0], rowptr[2], ... (first value of every lane's row pair)
   bool sweep_streamed = false;     // the plan matches column offsets only: values are streamed from val[] (spmv_vsweep_kernel)
   unsigned short *sweep_perm = nullptr;   // sweep kernel, rows of more than 8 entries: row pair each lane of a chunk owns (ncp x C/2)
   mutable int sweep_bpc[6] = {0, 0, 0, 0, 0, 0};
@@ -240,9 +243,10 @@ int launch_vsweep(const mk_matrix *A, int mode, double alpha, const double *x, d
 
 // CG step on vsweep matrices: K3 (p' = z + beta p, z = r or r * dinv) rides in the window fill of the product;
 // s = A p', partials of <s,p'>, <p',p'>; prologue = K3's convergence test on the 3 components of slab_in
+int build_vsweep_rowpair(mk_matrix *A);
 int launch_vsweep_cg_pdots(const mk_matrix *A, const double *r, const double *p_old, double *p_new, const double *dinv, double *s,
                            const double *slab_in, int nblocks_in, int stride_in, double *slab_out, PcgState *st, int two_norm,
-                           int rel_change, double *norms, int *nblocks);
+                           int rel_change, double *norms, int *nblocks, double *xupd = nullptr);
 
 // rows that repeat their neighbour's column list: groups of such rows, served by spmv_group_kernel (group.hip)
 int build_row_groups(mk_matrix *A);

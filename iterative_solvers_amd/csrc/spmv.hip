@@ -487,6 +487,7 @@ static int try_compress(mk_matrix *A) {
         MK_TRY(plan_sweep(A, tab, vals));
       } else {
         MK_TRY(plan_sweep(A, tab, std::vector<double>(), false));   // offsets from the table, values streamed
+        MK_TRY(build_vsweep_rowpair(A));
       }
     }
   }

@@ -48,16 +48,20 @@ __device__ __forceinline__ d2u_t vs_ld_u(const d2u_t *ptr) {   // keeps the 8-by
 //   p' = z + beta x instead of x (x = the old p; z = rhs, the residual, times `extra` = 1/diag per row when the Jacobi
 //   preconditioner is on: a third window stream), the block's own rows of p' go to pnew, then as MODE 1 on p':
 //   y = A p', partials of <y,p'>, <p',p'>.  flags: bit 0 two_norm, bit 1 rel_change.
+//   With xupd (the solution vector) the step's solution update rides here too, one kernel late: the fill has the old p in
+//   registers, so the block's own rows do xupd += alpha_prev * p_old (alpha_prev = the alpha of the step before, pending in
+//   the state record) and leave partials of <xupd,xupd>, <xupd,p'> from which the next kernel derives <x,x> after ITS update
+//   (hypre's rel_change test needs it); K2 then no longer reads p or touches x: 8 B per row less.
 // NL = 16-byte ring loads per thread per slab = ceil(sw / 2T); NVL = 16-byte value loads per thread per plane-step
 // (NVL * 2T >= len * C entries).
 template <int MODE, int NL, int NVL, int T, bool NT, bool PRE>
 __global__ __launch_bounds__(T, 2) void spmv_vsweep_kernel(
     const SweepArgs S, const SweepEntry *__restrict__ etab, int64_t nrows, int64_t ncols, int64_t nnz,
     const unsigned short *__restrict__ pat, const unsigned *__restrict__ pmask, int npat, const int *__restrict__ rowptr,
-    const double *__restrict__ val, const double *__restrict__ x, double *__restrict__ y, double alpha, double beta,
+    const int *__restrict__ rowpair, const double *__restrict__ val, const double *__restrict__ x, double *__restrict__ y, double alpha, double beta,
     double *__restrict__ slab, const int *__restrict__ done, const double *__restrict__ rhs, const double *__restrict__ extra,
     PcgState *st, const double *__restrict__ slab_in, int nblocks_in, int stride_in, double *__restrict__ pnew, int flags,
-    double *__restrict__ norms) {
+    double *__restrict__ norms, double *__restrict__ xupd) {
   if (done != nullptr && *done != 0) return;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   constexpr int C = 2 * T, NS = kNS, VCAP = NVL * 2 * T;
@@ -91,12 +95,13 @@ __global__ __launch_bounds__(T, 2) void spmv_vsweep_kernel(
     }
     if (conv || tiny_gamma) return;
     beta = gamma_new / gamma_old;
+    if (xupd != nullptr) alpha = st->x_pending ? al : 0.0;   // (alpha has no other use in this mode)
     __syncthreads();   // ring was reduction scratch
   }
   for (int i = tid; i < npat; i += T) smask[i] = pmask[i];
   const int nb = gridDim.x;   // multiple of 8; blocks of one XCD take neighbouring chunks of a plane (shared halos in its L2)
   const int lid = (blockIdx.x & 7) * (nb >> 3) + (blockIdx.x >> 3);
-  double acc0 = 0.0, acc1 = 0.0;
+  double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
   if (lid < S.ncp * S.nseg) {
     const int nr = (int)nrows;
     const int cp = lid % S.ncp, seg = lid / S.ncp;
@@ -109,9 +114,23 @@ __global__ __launch_bounds__(T, 2) void spmv_vsweep_kernel(
     const int rlast = (nr - 1) & ~1;
     const int elast = (int)max((int64_t)0, nnz - 1);   // val[elast + 1] is allocation slack (dev_alloc): never used by a row
 
+    // the one window piece of this lane that holds rows of the block's own chunk (pieces lie C = 2 T apart), and its offset
+    // in the chunk: the rows whose p' the lane stores and, with xupd, whose solution entries it updates
+    int oi = -1, ownoff = 0;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+      const int own = lr + i * 2 * T - S.wlo;
+      if (own >= 0 && own < rows_here && lr + i * 2 * T < sw) { oi = i; ownoff = own; }
+    }
+    const bool defx = (MODE == 3) && xupd != nullptr;
+    auto load_x = [&](int j) -> d2_t {
+      const int g = min(max(min(j, k1) * S.P + r0 + ownoff, 0), rlast);   // (plane k0 - 1 of the first segment lies before the array)
+      return vs_ld<NT>(reinterpret_cast<const d2_t *>(reinterpret_cast<const char *>(xupd) + ((unsigned)g << 3)));
+    };
     constexpr int NLR = (MODE == 3) ? NL : 1;              // second window stream (the residual) only in MODE 3
     constexpr int NLD = (MODE == 3 && PRE) ? NL : 1;       // third (1/diag per row) with the Jacobi preconditioner
-    auto load_slab = [&](int j, d2_t(&reg)[NL], d2_t(&regr)[NLR], d2_t(&regd)[NLD]) {   // window of plane j
+    auto load_slab = [&](int j, d2_t(&reg)[NL], d2_t(&regr)[NLR], d2_t(&regd)[NLD], d2_t &regx) {   // window of plane j
+      if (defx) regx = load_x(j);
       const int g0 = min(j, k1) * S.P + r0 - S.wlo + lr;
 #pragma unroll
       for (int i = 0; i < NL; i++) {
@@ -121,7 +140,7 @@ __global__ __launch_bounds__(T, 2) void spmv_vsweep_kernel(
         if (MODE == 3 && PRE) regd[i] = *reinterpret_cast<const d2_t *>(reinterpret_cast<const char *>(extra) + ((unsigned)g << 3));
       }
     };
-    auto write_slab = [&](int slot, int j, const d2_t(&reg)[NL], const d2_t(&regr)[NLR], const d2_t(&regd)[NLD]) {
+    auto write_slab = [&](int slot, int j, const d2_t(&reg)[NL], const d2_t(&regr)[NLR], const d2_t(&regd)[NLD], const d2_t &regx) {
       double *dst = ring + slot * sw + lr;
 #pragma unroll
       for (int i = 0; i < NL; i++) {
@@ -138,6 +157,20 @@ __global__ __launch_bounds__(T, 2) void spmv_vsweep_kernel(
               const int g = j * S.P + r0 + own;
               if (g + 1 < nr) vs_st<NT>(reinterpret_cast<d2_t *>(reinterpret_cast<char *>(pnew) + ((unsigned)g << 3)), v);
               else if (g < nr) *reinterpret_cast<double *>(reinterpret_cast<char *>(pnew) + ((unsigned)g << 3)) = v.x;
+              if (defx && i == oi && g < nr) {   // x += alpha_prev p_old on the same rows; partials of <x,x>, <x,p'>
+                d2_t xv = regx;
+                xv.x += alpha * reg[i].x;
+                xv.y += alpha * reg[i].y;
+                acc2 += xv.x * xv.x;
+                acc3 += xv.x * v.x;
+                if (g + 1 < nr) {
+                  acc2 += xv.y * xv.y;
+                  acc3 += xv.y * v.y;
+                  vs_st<NT>(reinterpret_cast<d2_t *>(reinterpret_cast<char *>(xupd) + ((unsigned)g << 3)), xv);
+                } else {
+                  *reinterpret_cast<double *>(reinterpret_cast<char *>(xupd) + ((unsigned)g << 3)) = xv.x;
+                }
+              }
             }
           }
           *reinterpret_cast<d2_t *>(dst + i * 2 * T) = v;
@@ -175,9 +208,11 @@ __global__ __launch_bounds__(T, 2) void spmv_vsweep_kernel(
       const int g = min(row_of(j), rlast);
       return vs_ld<NT>(reinterpret_cast<const unsigned *>(reinterpret_cast<const char *>(pat) + ((unsigned)g << 1)));
     };
-    auto load_rp = [&](int j) -> i2_t {        // rowptr[g], rowptr[g+1]; rowptr has nrows + 1 entries and slack behind
+    // first value of the lane's row pair: rowpair[g / 2] = rowptr[g] (g even), 2 B per row instead of 4; the second row's values
+    // follow the first row's, whose length is the popcount of its mask
+    auto load_rp = [&](int j) -> int {
       const int g = min(row_of(j), rlast);
-      return vs_ld<NT>(reinterpret_cast<const i2_t *>(reinterpret_cast<const char *>(rowptr) + ((unsigned)g << 2)));
+      return vs_ld<NT>(reinterpret_cast<const int *>(reinterpret_cast<const char *>(rowpair) + ((unsigned)g << 1)));
     };
     auto load_pair = [&](const double *p, int j) -> d2_t {
       const int g = min(row_of(j), rlast);
@@ -189,15 +224,16 @@ __global__ __launch_bounds__(T, 2) void spmv_vsweep_kernel(
     // register stages, used in place: ring stage (k mod 3) holds slab k+2 at step k; value stage ((k+1) mod 3) holds the
     // values of plane k+1 at step k, is written to LDS behind the step's first barrier and re-loaded with plane k+4
     d2_t st0[NL], st1[NL], st2[NL], rt0[NLR], rt1[NLR], rt2[NLR], dt0[NLD], dt1[NLD], dt2[NLD];
+    d2_t xt0 = {0.0, 0.0}, xt1 = xt0, xt2 = xt0;
     d2u_t vs0[NVL], vs1[NVL], vs2[NVL];
     int vb0 = span_begin(k0), vb1 = span_begin(k0 + 1), vb2 = span_begin(k0 + 2);
-    load_slab(k0 - 1, st0, rt0, dt0);
-    load_slab(k0, st1, rt1, dt1);
-    load_slab(k0 + 1, st2, rt2, dt2);
+    load_slab(k0 - 1, st0, rt0, dt0, xt0);
+    load_slab(k0, st1, rt1, dt1, xt1);
+    load_slab(k0 + 1, st2, rt2, dt2, xt2);
     load_vals(vb0, vs0);
-    write_slab(0, k0 - 1, st0, rt0, dt0);
-    write_slab(1, k0, st1, rt1, dt1);
-    write_slab(2, k0 + 1, st2, rt2, dt2);
+    write_slab(0, k0 - 1, st0, rt0, dt0, xt0);
+    write_slab(1, k0, st1, rt1, dt1, xt1);
+    write_slab(2, k0 + 1, st2, rt2, dt2, xt2);
     write_vals(vs0);
     int vbcur = vb0;                // span begin of the plane whose values sit in LDS
     load_vals(vb1, vs1);
@@ -207,28 +243,28 @@ __global__ __launch_bounds__(T, 2) void spmv_vsweep_kernel(
     int vbn = span_begin(k0 + 4);   // begin of the span loaded next (plane k+4 at step k), fetched one step early
     d2_t ax0 = {0.0, 0.0}, ax1 = ax0, ax2 = ax0, ex0 = ax0, ex1 = ax0, ex2 = ax0;
     unsigned id0 = load_ids(k0);
-    i2_t rp0 = load_rp(k0);
+    int rp0 = load_rp(k0);
     if (aux) ax0 = load_pair(aux, k0);
     if (kExtra && extra) ex0 = load_pair(extra, k0);
-    load_slab(k0 + 2, st0, rt0, dt0);
+    load_slab(k0 + 2, st0, rt0, dt0, xt0);
     unsigned id1 = load_ids(k0 + 1);
-    i2_t rp1 = load_rp(k0 + 1);
+    int rp1 = load_rp(k0 + 1);
     if (aux) ax1 = load_pair(aux, k0 + 1);
     if (kExtra && extra) ex1 = load_pair(extra, k0 + 1);
-    load_slab(k0 + 3, st1, rt1, dt1);
+    load_slab(k0 + 3, st1, rt1, dt1, xt1);
     unsigned id2 = load_ids(k0 + 2);
-    i2_t rp2 = load_rp(k0 + 2);
+    int rp2 = load_rp(k0 + 2);
     if (aux) ax2 = load_pair(aux, k0 + 2);
     if (kExtra && extra) ex2 = load_pair(extra, k0 + 2);
-    load_slab(k0 + 4, st2, rt2, dt2);
+    load_slab(k0 + 4, st2, rt2, dt2, xt2);
     __syncthreads();
 
     // vbcur: span begin of plane k (its values are in sval now).  vsn / vbs: value stage of plane k+1 and its span begin,
     // re-loaded with plane k+4 whose span begin is vbn (fetched during the previous step).
-    auto step = [&](int k, d2_t(&st)[NL], d2_t(&rt)[NLR], d2_t(&dt)[NLD], unsigned &idr, i2_t &rpr, d2_t &axr, d2_t &exr, d2u_t(&vsn)[NVL], int &vbs) {
+    auto step = [&](int k, d2_t(&st)[NL], d2_t(&rt)[NLR], d2_t(&dt)[NLD], d2_t &xt, unsigned &idr, int &rpr, d2_t &axr, d2_t &exr, d2u_t(&vsn)[NVL], int &vbs) {
       const int vbk = vbcur;
       const unsigned idc = idr;
-      const i2_t rpc = rpr;
+      const int rpc = rpr;
       const d2_t axc = axr, exc = exr;
       const int jb = (k - k0 + 1) & (NS - 1);   // ring slot of plane k
       if (live(k)) {
@@ -238,8 +274,8 @@ __global__ __launch_bounds__(T, 2) void spmv_vsweep_kernel(
         const unsigned mB = two ? smask[min(idc >> 16, (unsigned)npat - 1u)] : 0u;
         const char *wl = reinterpret_cast<const char *>(ring) + lr * 8;
         // positions of the two rows' first values in the stage; a row without a live partner reads its own
-        const int vA = rpc.x - vbk;
-        const int vB = two ? rpc.y - vbk : vA;
+        const int vA = rpc - vbk;
+        const int vB = two ? vA + __popc(mA) : vA;
         double s0 = 0.0, s1 = 0.0;
         for (int u0 = 0; u0 < S.len; u0 += 8) {
           typedef int i16_t __attribute__((ext_vector_type(16)));
@@ -298,14 +334,14 @@ __global__ __launch_bounds__(T, 2) void spmv_vsweep_kernel(
       }
       __syncthreads();   // everybody has read this plane's values
       // slab k+2 (loaded three steps ago) into the slot plane k-2 occupied; the values of plane k+1 into the stage
-      write_slab((k - k0 + 3) & (NS - 1), k + 2, st, rt, dt);
+      write_slab((k - k0 + 3) & (NS - 1), k + 2, st, rt, dt, xt);
       write_vals(vsn);
       // look-ahead loads into the registers just consumed: ids / row pointers / aux of plane k+3, slab k+5, values k+4
       idr = load_ids(k + 3);
       rpr = load_rp(k + 3);
       if (aux) axr = load_pair(aux, k + 3);
       if (kExtra && extra) exr = load_pair(extra, k + 3);
-      load_slab(k + 5, st, rt, dt);
+      load_slab(k + 5, st, rt, dt, xt);
       vbcur = vbs;
       vbs = vbn;
       load_vals(vbn, vsn);
@@ -313,20 +349,38 @@ __global__ __launch_bounds__(T, 2) void spmv_vsweep_kernel(
       __syncthreads();
     };
     for (int k = k0; k < k1; k += 3) {   // straight-line body: steps at or behind k1 compute nothing (live() is false)
-      step(k, st0, rt0, dt0, id0, rp0, ax0, ex0, vs1, vb1);
-      step(k + 1, st1, rt1, dt1, id1, rp1, ax1, ex1, vs2, vb2);
-      step(k + 2, st2, rt2, dt2, id2, rp2, ax2, ex2, vs0, vb0);
+      step(k, st0, rt0, dt0, xt0, id0, rp0, ax0, ex0, vs1, vb1);
+      step(k + 1, st1, rt1, dt1, xt1, id1, rp1, ax1, ex1, vs2, vb2);
+      step(k + 2, st2, rt2, dt2, xt2, id2, rp2, ax2, ex2, vs0, vb0);
     }
   }
   if (MODE != 0) {
     __syncthreads();
-    double w[2] = {acc0, acc1};
-    block_sum<2, T>(w, ring);
+    double w[4] = {acc0, acc1, acc2, acc3};
+    block_sum<4, T>(w, ring);
     if (threadIdx.x == 0) {
       slab[0 * kSlabStride + blockIdx.x] = w[0];
       if (MODE == 1 || MODE == 3) slab[1 * kSlabStride + blockIdx.x] = w[1];
+      if (MODE == 3 && xupd != nullptr) {
+        slab[2 * kSlabStride + blockIdx.x] = w[2];
+        slab[3 * kSlabStride + blockIdx.x] = w[3];
+      }
     }
   }
+}
+
+// rowpair[i] = rowptr[2 i]: where the values of rows 2 i, 2 i + 1 (one lane's pair) begin
+__global__ void rowpair_kernel(int64_t nrows, const int *__restrict__ rowptr, int *__restrict__ rowpair) {
+  const int64_t np = (nrows + 1) / 2;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < np; i += (int64_t)gridDim.x * blockDim.x) rowpair[i] = rowptr[2 * i];
+}
+int build_vsweep_rowpair(mk_matrix *A) {
+  if (A->rowpair || !A->sweep || !A->sweep_streamed) return MK_OK;
+  const int64_t np = (A->nrows + 1) / 2;
+  MK_TRY(dev_alloc(&A->rowpair, (size_t)np + 1));
+  hipLaunchKernelGGL(rowpair_kernel, dim3((unsigned)std::min<int64_t>((np + 255) / 256, 8192)), dim3(256), 0, ctx().stream, A->nrows, A->rowptr, A->rowpair);
+  MK_HIP(hipGetLastError());
+  return MK_OK;
 }
 
 // CG arguments of MODE 3 (unused by the other modes)
@@ -337,6 +391,7 @@ struct VsCg {
   double *pnew = nullptr;
   int flags = 0;
   double *norms = nullptr;
+  double *xupd = nullptr;
 };
 
 template <int MODE, int NL, int NVL, int T, bool PRE>
@@ -352,8 +407,8 @@ static int launch_vsweep_t(const mk_matrix *A, const SweepArgs &S, size_t lds, i
     lds_max[nt ? 1 : 0] = lds;
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(T), lds, c.stream, S, A->etab, A->nrows, A->ncols, A->nnz, A->pat, A->pmask,
-                     A->npat, A->rowptr, A->val, x, y, alpha, beta, slab, done, rhs, extra, cg.st, cg.slab_in, cg.nblocks_in,
-                     cg.stride_in, cg.pnew, cg.flags, cg.norms);
+                     A->npat, A->rowptr, A->rowpair, A->val, x, y, alpha, beta, slab, done, rhs, extra, cg.st, cg.slab_in, cg.nblocks_in,
+                     cg.stride_in, cg.pnew, cg.flags, cg.norms, cg.xupd);
   MK_HIP(hipGetLastError());
   return MK_OK;
 }
@@ -362,7 +417,7 @@ template <int MODE, bool PRE = false>
 static int launch_vsweep_m(const mk_matrix *A, double alpha, const double *x, double beta, double *y, double *slab, const int *done,
                            int *nblocks, const double *rhs, const double *extra, const VsCg &cg = VsCg()) {
   Context &c = ctx();
-  if (!A->sweep || !A->sweep_streamed || !A->pat)
+  if (!A->sweep || !A->sweep_streamed || !A->pat || !A->rowpair)
     return fail(MK_ERR_UNSUPPORTED, "spmv: MK_SPMV_VSWEEP needs rows that are sub-lists, by column offset, of one grid pattern of at most 8 entries");
   SweepArgs S = *A->sweep;
   const int T = S.C / 2;
@@ -413,8 +468,9 @@ int launch_vsweep(const mk_matrix *A, int mode, double alpha, const double *x, d
 // (z = r, or r * dinv per row), s = A p_new, partials of <s, p_new>, <p_new, p_new> into slab_out; prologue = K3's
 int launch_vsweep_cg_pdots(const mk_matrix *A, const double *r, const double *p_old, double *p_new, const double *dinv, double *s,
                            const double *slab_in, int nblocks_in, int stride_in, double *slab_out, PcgState *st, int two_norm,
-                           int rel_change, double *norms, int *nblocks) {
+                           int rel_change, double *norms, int *nblocks, double *xupd) {
   VsCg cg;
+  cg.xupd = xupd;
   cg.st = st; cg.slab_in = slab_in; cg.nblocks_in = nblocks_in; cg.stride_in = stride_in; cg.pnew = p_new;
   cg.flags = (two_norm ? 1 : 0) | (rel_change ? 2 : 0); cg.norms = norms;
   if (dinv) return launch_vsweep_m<3, true>(A, 1.0, p_old, 0.0, s, slab_out, nullptr, nblocks, r, dinv, cg);
