@@ -173,7 +173,7 @@ static int run_distributed(const char *mtx, const char *bfile, const char *xfile
   double *hb = NULL, *hx = NULL;
   if (bfile) {                                                          /* :413-418: every rank takes its slice */
     unsigned int m = 0;
-    if (fast_load_from_array_file(bfile, &hb, &m) != 0) return 1;
+    if (load_array_file(bfile, &hb, &m) != 0) return 1;
     if ((long long)m < n) { fprintf(stderr, "%s holds %u values, %lld needed\n", bfile, m, n); return 1; }
     CK(mk_vector_set(b, hb + lo));
   } else {
@@ -181,7 +181,7 @@ static int run_distributed(const char *mtx, const char *bfile, const char *xfile
   }
   if (xfile) {
     unsigned int m = 0;
-    if (fast_load_from_array_file(xfile, &hx, &m) != 0) return 1;
+    if (load_array_file(xfile, &hx, &m) != 0) return 1;
     if ((long long)m < n) { fprintf(stderr, "%s holds %u values, %lld needed\n", xfile, m, n); return 1; }
     CK(mk_vector_set(x, hx + lo));
   } else {
@@ -342,7 +342,7 @@ int main(int argc, char *argv[]) {
   CK(mk_vector_create(n, &x));
   if (bfile) {                                                        /* :413-418 */
     double *h = NULL; unsigned int m = 0;
-    if (fast_load_from_array_file(bfile, &h, &m) != 0) return 1;
+    if (load_array_file(bfile, &h, &m) != 0) return 1;
     if (m < n) { fprintf(stderr, "%s holds %u values, %u needed\n", bfile, m, n); return 1; }
     CK(mk_vector_set(b, h));
     free(h);
@@ -351,7 +351,7 @@ int main(int argc, char *argv[]) {
   }
   if (xfile) {                                                        /* :431-436 */
     double *h = NULL; unsigned int m = 0;
-    if (fast_load_from_array_file(xfile, &h, &m) != 0) return 1;
+    if (load_array_file(xfile, &h, &m) != 0) return 1;
     if (m < n) { fprintf(stderr, "%s holds %u values, %u needed\n", xfile, m, n); return 1; }
     CK(mk_vector_set(x, h));
     free(h);

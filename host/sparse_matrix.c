@@ -239,7 +239,7 @@ int fast_load_from_mtx_file(const char *path, SparseMatrixCOO *coo) {
 /* sparse_matrix.c:34-90: `m` values, one per line, of a Matrix Market array file (only the
  * first column is meaningful in the reference as well: it ignores n, :72-76).  The validity
  * test uses || where the reference has &&. */
-int fast_load_from_array_file(const char *path, double **vals, unsigned int *count) {
+int load_array_file(const char *path, double **vals, unsigned int *count) {
   FILE *f = fopen(path, "r");
   if (!f) { fprintf(stderr, "Could not open file: %s \n", path); return 1; }
   MM_typecode tc;
@@ -258,6 +258,14 @@ int fast_load_from_array_file(const char *path, double **vals, unsigned int *cou
   if (count) *count = m;
   fclose(f);
   return 0;
+}
+
+/* the reference's own signature (sparse_matrix.h:59, called at solvers.c:206-210 with mtx_ext, which the reference fixes at 1,
+ * solvers.c:88): an unpatched call site compiles and links against this library.  ext_factor > 1 asked the reference's
+ * loader for its "extend" blow-up (sparse_matrix.c:92-109), a dead feature that is refused here. */
+int fast_load_from_array_file(const char *path, double **vals, const int ext_factor) {
+  if (ext_factor != 1) { fprintf(stderr, "%s: ext_factor %d is not supported (the reference fixes it at 1)\n", path, ext_factor); return 7; }
+  return load_array_file(path, vals, NULL);
 }
 
 /* device stable sort by row: sparse_matrix.c:419-529 */

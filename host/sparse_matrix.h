@@ -19,7 +19,8 @@
 extern "C" {
 #endif
 int fast_load_from_mtx_file(const char *mtx_filepath, SparseMatrixCOO *coo_matrix);
-int fast_load_from_array_file(const char *mtx_filepath, double **vals, unsigned int *count);
+int fast_load_from_array_file(const char *mtx_filepath, double **vals, const int ext_factor);   /* the reference's signature; ext_factor must be 1 */
+int load_array_file(const char *mtx_filepath, double **vals, unsigned int *count);               /* the same, also returning the number of values */
 int sort_coo_row(const SparseMatrixCOO *coo_matrix, SparseMatrixCOO *s_coo_matrix);
 int convert_coo_to_csr(const SparseMatrixCOO *coo_matrix, SparseMatrixCSR *csr_matrix, int free_coo);
 void free_coo(SparseMatrixCOO *m);

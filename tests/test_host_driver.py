@@ -22,7 +22,8 @@ def _host():
     mk.load()
     L = C.CDLL(os.path.join(HOST, "libmkhost.so"))
     L.fast_load_from_mtx_file.argtypes = [C.c_char_p, C.POINTER(mk.COO)]
-    L.fast_load_from_array_file.argtypes = [C.c_char_p, C.POINTER(C.POINTER(C.c_double)), C.POINTER(C.c_uint)]
+    L.load_array_file.argtypes = [C.c_char_p, C.POINTER(C.POINTER(C.c_double)), C.POINTER(C.c_uint)]
+    L.fast_load_from_array_file.argtypes = [C.c_char_p, C.POINTER(C.POINTER(C.c_double)), C.c_int]   # the reference's signature
     return L
 
 
@@ -226,8 +227,11 @@ def test_loader_errors_are_returned_not_fatal(tmp_path):
     p = tmp_path / "array.mtx"
     p.write_text("%%MatrixMarket matrix array real general\n% rhs\n3 1\n1.5\n-2\n3e2\n")
     v, cnt = C.POINTER(C.c_double)(), C.c_uint()
-    assert L.fast_load_from_array_file(str(p).encode(), C.byref(v), C.byref(cnt)) == 0
+    assert L.load_array_file(str(p).encode(), C.byref(v), C.byref(cnt)) == 0
     assert cnt.value == 3 and [v[i] for i in range(3)] == [1.5, -2.0, 300.0]
+    v2 = C.POINTER(C.c_double)()
+    assert L.fast_load_from_array_file(str(p).encode(), C.byref(v2), 1) == 0 and [v2[i] for i in range(3)] == [1.5, -2.0, 300.0]
+    assert L.fast_load_from_array_file(str(p).encode(), C.byref(v2), 2) != 0          # the reference's dead 'extend' factor
 
 
 def _write_poisson(path, nx, ny, shuffle_seed=None):
@@ -527,3 +531,22 @@ def test_driver_reads_a_shuffled_symmetric_file_with_the_parallel_parser(tmp_pat
     it = int(re.search(r"^Iterations = (\d+)$", out.stdout, re.M).group(1))
     o = oracle.pcg(rp, ci, v, np.ones(n), tol=1e-8, precond=1, maxit=3000)
     assert abs(it - o["iterations"]) <= 2, (it, o["iterations"])
+
+
+def test_reference_call_sites_compile_against_the_host_header(tmp_path):
+    """the four loader / conversion calls the reference driver and its dead alternative driver make (solvers.c:196-210,
+    main.c:64: results ignored, third argument of the array loader an int) compile without a diagnostic against
+    host/sparse_matrix.h -- the host API is the reference's, argument for argument"""
+    src = tmp_path / "calls.c"
+    src.write_text('#include "sparse_matrix.h"\n'
+                   "void driver(const char *m, const char *b) {\n"
+                   "  SparseMatrixCOO t, c; SparseMatrixCSR r; double *rhs; const int mtx_ext = 1;\n"
+                   "  fast_load_from_mtx_file(m, &t);\n"
+                   "  sort_coo_row(&t, &c);\n"
+                   "  fast_load_from_array_file(b, &rhs, mtx_ext);\n"
+                   "  convert_coo_to_csr(&c, &r, 1);\n"
+                   "  (void)get_multiple_of_align_size(100);\n"
+                   "}\n")
+    out = subprocess.run(["gcc", "-std=gnu11", "-Wall", "-Wextra", "-Werror", "-Dalign_size=64", "-I", HOST, "-I", os.path.join(ROOT, "include"),
+                          "-c", str(src), "-o", str(tmp_path / "calls.o")], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
