@@ -127,7 +127,13 @@ struct LocalWorld {
   int nranks = 0;
   std::vector<mk_comm *> comms;
   std::vector<mk_dist_matrix *> mats;   // registered by rank
-  double **d_ptrs = nullptr;            // device array of nranks pointers (all-reduce emulation)
+  // all-reduce emulation: device tables of nranks pointers each.  A solver all-reduces the same few buffer sets over and over,
+  // so a table is uploaded once and found again by its contents (no copy, no host wait per reduction: with one the
+  // local world stalled the GPU twice per CG iteration, which no RCCL run does)
+  static constexpr int kPtrTabs = 4;
+  double **d_ptrs = nullptr;            // kPtrTabs x nranks
+  std::vector<double *> h_ptrs[kPtrTabs];
+  int next_tab = 0;
   // the local world's stand-in for the communication stream: halo copies and the off-rank products of the fused CG step
   // run here, beside the diag sweeps on the main stream, exactly as they do on the RCCL communication stream
   hipStream_t side = nullptr;
@@ -519,10 +525,18 @@ static int all_reduce(int R, mk_dist_matrix **A, double **bufs, int count) {
   if (A[0]->comm == nullptr) return MK_OK;
   if (A[0]->comm->local) {
     LocalWorld *W = A[0]->comm->world;
-    MK_HIP(hipMemcpyAsync(W->d_ptrs, bufs, sizeof(double *) * R, hipMemcpyHostToDevice, c.stream));
-    hipLaunchKernelGGL(local_allreduce_kernel, dim3(1), dim3(64), 0, c.stream, W->d_ptrs, R, count);
-    // bufs is a host array owned by the caller and may be reused: the copy above must have left it
-    MK_HIP(hipStreamSynchronize(c.stream));
+    int tab = -1;
+    for (int t = 0; t < LocalWorld::kPtrTabs && tab < 0; t++)
+      if ((int)W->h_ptrs[t].size() == R && std::equal(bufs, bufs + R, W->h_ptrs[t].begin())) tab = t;
+    if (tab < 0) {   // a new set of buffers: take the next table (whoever used it last has long finished: drain to be sure)
+      tab = W->next_tab;
+      W->next_tab = (W->next_tab + 1) % LocalWorld::kPtrTabs;
+      MK_HIP(hipStreamSynchronize(c.stream));
+      W->h_ptrs[tab].assign(bufs, bufs + R);
+      MK_HIP(hipMemcpyAsync(W->d_ptrs + (size_t)tab * R, W->h_ptrs[tab].data(), sizeof(double *) * R, hipMemcpyHostToDevice, c.stream));
+      MK_HIP(hipStreamSynchronize(c.stream));
+    }
+    hipLaunchKernelGGL(local_allreduce_kernel, dim3(1), dim3(64), 0, c.stream, W->d_ptrs + (size_t)tab * R, R, count);
     return MK_OK;
   }
   MK_NCCL(g_rccl.AllReduce(bufs[0], bufs[0], (size_t)count, ncclDouble, ncclSum, A[0]->comm->coll, c.stream));
@@ -636,7 +650,7 @@ int mk_comm_create_local(int nranks, mk_comm **comms) {
   LocalWorld *W = new LocalWorld();
   W->nranks = nranks;
   W->mats.assign(nranks, nullptr);
-  MK_TRY(dev_alloc(&W->d_ptrs, (size_t)nranks));
+  MK_TRY(dev_alloc(&W->d_ptrs, (size_t)nranks * LocalWorld::kPtrTabs));
   MK_HIP(hipStreamCreateWithFlags(&W->side, hipStreamNonBlocking));
   register_side_stream(W->side);
   MK_HIP(hipEventCreateWithFlags(&W->ev_ready, hipEventDisableTiming));

@@ -15,4 +15,9 @@ for rep in range(2):
     x.fill(0.0)
     S.solve(A, b, x)
 kt = S.kernel_timing()
+# the plain product + dots as its own launches (bench.py's roofline.spmv_only), so that its counters are in the same passes
+xs, ys = mk.Vector(n, fill=1.0), mk.Vector(n)
+for _ in range(12):
+    A.spmv_dot(xs, ys, want=False)
+mk.synchronize()
 print(f"{nx}x{ny}x{nz} seed={seed} kernel={A.info().kernel} ms:", [round(m, 4) for m, c in kt], "sum", round(sum(m for m, c in kt), 4), flush=True)

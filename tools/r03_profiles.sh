@@ -1,0 +1,25 @@
+#!/bin/bash
+# Round-3 evidence: (1) rocprofv3 kernel stats of the default bench.py run, (2) HBM traffic by PMC passes (FETCH_SIZE and
+# WRITE_SIZE in separate runs, as MI355X_MICROARCH.md prescribes) of the CG loops bench.py times, (3) the same for the
+# R-MAT conversion + product and for the FE-like matrix the row-group kernel serves, (4) kernel trace of the row-block probe.
+# usage (on the GPU box): bash tools/r03_profiles.sh   -> gpurun_out/r03_*
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out
+mkdir -p $O
+timeout -k 10 500 rocprofv3 --kernel-trace --stats -d $O/r03_bench_prof -o bench --output-format csv -- python3 $R/bench.py --no-cpu-baseline > $O/r03_bench_under_rocprof.json 2> $O/r03_bench_under_rocprof.err || exit 1
+for w in "512x512x512 0 0" "512x512x512 1 0"; do
+  tag=$(echo $w | tr ' ' '_')
+  for ctr in "FETCH_SIZE" "WRITE_SIZE" "TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum"; do
+    c1=$(echo $ctr | cut -d' ' -f1)
+    timeout -s KILL 120 rocprofv3 --pmc $ctr -d $O/r03_pmc_${tag}_$c1 -o pmc --output-format csv -- python3 $R/tools/cgk_probe.py $w > /dev/null 2>&1 || exit 1
+  done
+done
+for ctr in "FETCH_SIZE" "WRITE_SIZE" "TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum"; do
+  c1=$(echo $ctr | cut -d' ' -f1)
+  timeout -s KILL 200 rocprofv3 --pmc $ctr -d $O/r03_pmc_convert_$c1 -o pmc --output-format csv -- python3 $R/tools/rmat_probe.py > /dev/null 2>&1 || exit 1
+  timeout -s KILL 200 rocprofv3 --pmc $ctr -d $O/r03_pmc_group_$c1 -o pmc --output-format csv -- python3 $R/tools/group_probe.py 500000 26 300 > /dev/null 2>&1 || exit 1
+done
+timeout -k 10 200 python3 $R/tools/dist_probe.py 512 512 512 8 100 > $O/r03_dist_probe_plain.txt 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace -d $O/r03_dist_prof -o dist --output-format csv -- python3 $R/tools/dist_probe.py 512 512 512 8 40 > $O/r03_dist_probe.txt 2>&1 || exit 1
+echo done
