@@ -324,6 +324,11 @@ int mk_dist_spmv(int nranks_here, mk_dist_matrix **A, mk_vector **x, mk_vector *
 int mk_dist_pcg_solve(int nranks_here, mk_pcg **solvers, mk_dist_matrix **A, mk_vector **b, mk_vector **x);
 /* plain Jacobi (extension id 70) on the distributed operator; residual all-reduced every check_every iterations */
 int mk_dist_jacobi_solve(int nranks_here, mk_jacobi **solvers, mk_dist_matrix **A, mk_vector **b, mk_vector **x);
+/* HYPRE_ParCSRBiCGSTABSetup + Solve (solvers.c:517-564) and HYPRE_ParCSRGMRESSetup + Solve (solvers.c:1183-1245) on the
+ * distributed operator; no setup call (the work vectors live for the solve); settings and results through the
+ * mk_bicgstab_* / mk_gmres_* setters and getters */
+int mk_dist_bicgstab_solve(int nranks_here, mk_bicgstab **solvers, mk_dist_matrix **A, mk_vector **b, mk_vector **x);
+int mk_dist_gmres_solve(int nranks_here, mk_gmres **solvers, mk_dist_matrix **A, mk_vector **b, mk_vector **x);
 
 /* ---- exchange planning, host only (no GPU): the host half of the ParCSR communication package that
  *      HYPRE_IJMatrixAssemble builds (solvers.c:362); mk_dist_matrix_create runs exactly these -------------- */

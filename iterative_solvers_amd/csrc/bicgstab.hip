@@ -14,6 +14,9 @@
 #include <cfloat>
 #include <cmath>
 
+#include <vector>
+
+#include "dist_internal.h"
 #include "krylov_kernels.h"
 
 namespace mk {
@@ -81,10 +84,10 @@ static __global__ __launch_bounds__(kVecThreads) void bicg_init_vectors_kernel(i
   }
 }
 
-static __global__ __launch_bounds__(kVecThreads) void bicg_init_scalars_kernel(const double *slab, int nblocks, double tol, BicgState *st, double *norms) {
+static __global__ __launch_bounds__(kVecThreads) void bicg_init_scalars_kernel(const double *slab, int nblocks, int stride, double tol, BicgState *st, double *norms) {
   __shared__ double smem[2 * (kVecThreads / 64)];
   double v[2];
-  reduce_slab<2, kVecThreads>(slab, nblocks, kSlabStride, v, smem);
+  reduce_slab<2, kVecThreads>(slab, nblocks, stride, v, smem);
   if (threadIdx.x == 0) {
     BicgState s;
     memset(&s, 0, sizeof(s));
@@ -139,11 +142,11 @@ static __global__ __launch_bounds__(kVecThreads) void bicg_step1_kernel(int64_t 
 // the true residual replaces r in between: then the dot kernel behind it overwrites them)
 static __global__ __launch_bounds__(kVecThreads) void bicg_step2_kernel(int64_t n, const double *__restrict__ s, const double *__restrict__ r0, double *__restrict__ x,
                                                                         double *__restrict__ r, const double *__restrict__ slab_in,
-                                                                        int nblocks_in, double *__restrict__ slab_out, BicgState *st, int nt) {
+                                                                        int nblocks_in, int stride_in, double *__restrict__ slab_out, BicgState *st, int nt) {
   if (st->done != 0) return;
   __shared__ double smem[2 * (kVecThreads / 64)];
   double d[2];
-  reduce_slab<2, kVecThreads>(slab_in, nblocks_in, kSlabStride, d, smem);
+  reduce_slab<2, kVecThreads>(slab_in, nblocks_in, stride_in, d, smem);
   const double gamma = (d[0] == 0.0 && d[1] == 0.0) ? 0.0 : d[0] / d[1];
   double v[2] = {0.0, 0.0};
   const int64_t n2 = n >> 1;
@@ -204,11 +207,11 @@ static __global__ void copy_unless_kernel(double *__restrict__ dst, const double
 // Convergence on the true residual; beta = (<r0,r>/res)(alpha/gamma); p = beta (p - gamma q) + r
 static __global__ __launch_bounds__(kVecThreads) void bicg_step3_kernel(int64_t n, const double *__restrict__ r, const double *__restrict__ q,
                                                                         double *__restrict__ p, const double *__restrict__ slab_in,
-                                                                        int nblocks_in, BicgState *st, int nt, int parity) {
+                                                                        int nblocks_in, int stride_in, BicgState *st, int nt, int parity) {
   if (block_flag_raised(&st->done)) return;
   __shared__ double smem[2 * (kVecThreads / 64)];
   double d[2];
-  reduce_slab<2, kVecThreads>(slab_in, nblocks_in, kSlabStride, d, smem);
+  reduce_slab<2, kVecThreads>(slab_in, nblocks_in, stride_in, d, smem);
   const bool leader = (blockIdx.x == 0 && threadIdx.x == 0);
   // skip_true, alpha, gamma and resv[parity] were written by earlier launches and are not written here
   const bool cand = (st->skip_true == 0);
@@ -348,7 +351,7 @@ int mk_bicgstab_solve(mk_bicgstab *S, const mk_matrix *A, const mk_vector *b, mk
   hipLaunchKernelGGL(copy_kernel, grid, dim3(256), 0, c.stream, S->r0, b->d, n);
   MK_TRY(launch_spmv(A, -1.0, x->d, 1.0, S->r0));
   hipLaunchKernelGGL(bicg_init_vectors_kernel, grid, block, 0, c.stream, n, b->d, S->r0, S->r, S->p, S->slab1);
-  hipLaunchKernelGGL(bicg_init_scalars_kernel, dim3(1), block, 0, c.stream, S->slab1, vb, S->tol, S->state, S->norms);
+  hipLaunchKernelGGL(bicg_init_scalars_kernel, dim3(1), block, 0, c.stream, S->slab1, vb, kSlabStride, S->tol, S->state, S->norms);
 
   bool stop = false;
   for (int it = 0; it < S->max_iter && !stop; it++) {
@@ -358,13 +361,13 @@ int mk_bicgstab_solve(mk_bicgstab *S, const mk_matrix *A, const mk_vector *b, mk
     hipLaunchKernelGGL(bicg_step1_kernel, grid, block, 0, c.stream, n, S->p, S->q, x->d, S->r, S->slab1, vb, S->state, nt, it & 1);
     MK_TRY(launch_spmv(A, 1.0, S->r, 0.0, S->s, done));
     hipLaunchKernelGGL(dot2_kernel, grid, block, 0, c.stream, n, S->r, S->s, S->s, S->s, S->slab2, done, nt);
-    hipLaunchKernelGGL(bicg_step2_kernel, grid, block, 0, c.stream, n, S->s, S->r0, x->d, S->r, S->slab2, vb, S->slab3, S->state, nt);
+    hipLaunchKernelGGL(bicg_step2_kernel, grid, block, 0, c.stream, n, S->s, S->r0, x->d, S->r, S->slab2, vb, kSlabStride, S->slab3, S->state, nt);
     hipLaunchKernelGGL(bicg_norm_kernel, dim3(1), block, 0, c.stream, S->slab3 + kSlabStride, vb, S->state, S->norms);
     // only when the recursive residual passed: r = b - A x (skip_true is 1 otherwise, and after a stop)
     hipLaunchKernelGGL(copy_unless_kernel, grid, dim3(256), 0, c.stream, S->r, b->d, n, skip);
     MK_TRY(launch_spmv(A, -1.0, x->d, 1.0, S->r, skip));
     hipLaunchKernelGGL(dot2_kernel, grid, block, 0, c.stream, n, S->r0, S->r, S->r, S->r, S->slab3, skip, nt);   // only behind a true residual
-    hipLaunchKernelGGL(bicg_step3_kernel, grid, block, 0, c.stream, n, S->r, S->q, S->p, S->slab3, vb, S->state, nt, it & 1);
+    hipLaunchKernelGGL(bicg_step3_kernel, grid, block, 0, c.stream, n, S->r, S->q, S->p, S->slab3, vb, kSlabStride, S->state, nt, it & 1);
     if ((it + 1) % S->check_every == 0) {
       MK_HIP(hipMemcpyAsync(&hst[0], S->state, sizeof(BicgState), hipMemcpyDeviceToHost, c.stream));
       MK_HIP(hipStreamSynchronize(c.stream));
@@ -413,6 +416,148 @@ int mk_bicgstab_get_residual_history(const mk_bicgstab *S, double *norms, int ca
     MK_HIP(hipStreamSynchronize(ctx().stream));
   }
   return count;
+}
+
+// ---------------------------------------------------------------------------- row blocks
+// HYPRE_ParCSRBiCGSTABSetup + Solve over the row blocks (solvers.c:517-564 with num_procs > 1).  The loop of
+// mk_bicgstab_solve with every product done by dist_spmv (halo of the operand beside the diag-block product) and every
+// reduction folded to one value per component (finalize_slab_kernel), all-reduced, and read by the next kernel's prologue
+// as a one-block slab: five all-reduces per iteration, as many as hypre's own inner products.  The scalars live in one
+// device record per rank; they derive from all-reduced values only, so every rank takes the same branches.
+int mk_dist_bicgstab_solve(int R, mk_bicgstab **solvers, mk_dist_matrix **A, mk_vector **b, mk_vector **x) {
+  MK_REQUIRE_INIT();
+  MK_TRY(dist_check_ranks("mk_dist_bicgstab_solve", R, A));
+  if (!solvers || !b || !x) return fail(MK_ERR_INVALID, "mk_dist_bicgstab_solve: null argument");
+  Context &c = ctx();
+  mk_bicgstab *S0 = solvers[0];
+  for (int r = 0; r < R; r++) {
+    if (!solvers[r] || !b[r] || !x[r]) return fail(MK_ERR_INVALID, "mk_dist_bicgstab_solve: null argument");
+    if (b[r]->n != A[r]->n_local || x[r]->n != A[r]->n_local || x[r]->cap < A[r]->n_local + A[r]->n_ghost)
+      return fail(MK_ERR_INVALID, "mk_dist_bicgstab_solve: vectors must come from mk_dist_vector_create of the same matrix");
+    if (solvers[r]->max_iter != S0->max_iter || solvers[r]->tol != S0->tol || solvers[r]->check_every != S0->check_every)
+      return fail(MK_ERR_INVALID, "mk_dist_bicgstab_solve: ranks disagree on solver settings");
+  }
+  const bool want_norms = S0->logging > 0 || S0->print_level > 0;
+  struct Work {
+    double *r0 = nullptr, *r = nullptr, *p = nullptr, *q = nullptr, *s = nullptr, *slab1 = nullptr, *slab2 = nullptr, *slab3 = nullptr;
+    double *buf = nullptr, *norms = nullptr;
+    BicgState *state = nullptr;
+    void release() {
+      dev_free(r0); dev_free(r); dev_free(p); dev_free(q); dev_free(s); dev_free(slab1); dev_free(slab2); dev_free(slab3);
+      dev_free(buf); dev_free(norms); dev_free(state);
+    }
+  };
+  std::vector<Work> W(R);
+  std::vector<double *> pv(R), rv(R), qv(R), sv(R), xv(R), bufs(R);
+  std::vector<const int *> done(R), skip(R);
+  std::vector<int> vb(R), nt(R);
+  int rc = MK_OK;
+  auto cleanup = [&]() { (void)hipDeviceSynchronize(); for (auto &w : W) w.release(); };
+#define MK_D(expr) do { rc = (expr); if (rc != MK_OK) { cleanup(); return rc; } } while (0)
+#define MK_DH(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return fail(MK_ERR_HIP, "%s -> %s", #expr, hipGetErrorString(e_)); } } while (0)
+  for (int r = 0; r < R; r++) {
+    const size_t nl = (size_t)A[r]->n_local, ne = (size_t)(A[r]->n_local + A[r]->n_ghost);
+    MK_D(dev_alloc(&W[r].r0, nl));
+    MK_D(dev_alloc(&W[r].r, ne));    // operands of a product carry their ghosts behind the owned rows
+    MK_D(dev_alloc(&W[r].p, ne));
+    MK_D(dev_alloc(&W[r].q, nl));
+    MK_D(dev_alloc(&W[r].s, nl));
+    MK_D(dev_alloc(&W[r].slab1, (size_t)2 * kSlabStride));
+    MK_D(dev_alloc(&W[r].slab2, (size_t)2 * kSlabStride));
+    MK_D(dev_alloc(&W[r].slab3, (size_t)2 * kSlabStride));
+    MK_D(dev_alloc(&W[r].buf, 8));
+    MK_D(dev_alloc(&W[r].state, 1));
+    if (want_norms) MK_D(dev_alloc(&W[r].norms, (size_t)S0->max_iter + 1));
+    MK_D(analyse_matrix(&A[r]->diag));
+    pv[r] = W[r].p; rv[r] = W[r].r; qv[r] = W[r].q; sv[r] = W[r].s; xv[r] = x[r]->d; bufs[r] = W[r].buf;
+    done[r] = &W[r].state->done; skip[r] = &W[r].state->skip_true;
+    vb[r] = vec_blocks(A[r]->n_local);
+    nt[r] = (int)nt_rows(A[r]->n_local);
+    solvers[r]->iterations = 0; solvers[r]->rel_res_norm = 0.0; solvers[r]->converged = 0; solvers[r]->breakdown = 0;
+  }
+  const dim3 block(kVecThreads);
+  // fold the two components of a slab and all-reduce them into buf[0..1] of every rank
+  auto reduce2 = [&](auto slab_of) -> int {
+    for (int r = 0; r < R; r++)
+      hipLaunchKernelGGL((finalize_slab_kernel<2>), dim3(1), block, 0, c.stream, slab_of(r), vb[r], W[r].buf);
+    return dist_all_reduce(R, A, bufs.data(), 2);
+  };
+  BicgState *hst = static_cast<BicgState *>(c.pinned);
+
+  // r0 = b - A x;  r = p = r0;  <b,b>, <r0,r0>
+  {
+    std::vector<double *> r0v(R);
+    for (int r = 0; r < R; r++) {
+      r0v[r] = W[r].r0;
+      if (A[r]->n_local) hipLaunchKernelGGL(copy_kernel, dim3(vb[r]), dim3(256), 0, c.stream, W[r].r0, b[r]->d, A[r]->n_local);
+    }
+    MK_D(dist_spmv(R, A, xv.data(), r0v.data(), -1.0, 1.0, nullptr));
+  }
+  for (int r = 0; r < R; r++)
+    hipLaunchKernelGGL(bicg_init_vectors_kernel, dim3(vb[r]), block, 0, c.stream, A[r]->n_local, b[r]->d, W[r].r0, W[r].r, W[r].p, W[r].slab1);
+  MK_D(reduce2([&](int r) { return W[r].slab1; }));
+  for (int r = 0; r < R; r++)
+    hipLaunchKernelGGL(bicg_init_scalars_kernel, dim3(1), block, 0, c.stream, W[r].buf, 1, 1, S0->tol, W[r].state, W[r].norms);
+
+  bool stop = false;
+  for (int it = 0; it < S0->max_iter && !stop; it++) {
+    MK_D(dist_spmv(R, A, pv.data(), qv.data(), 1.0, 0.0, done.data()));                  // q = A p
+    for (int r = 0; r < R; r++)
+      hipLaunchKernelGGL(dot2_kernel, dim3(vb[r]), block, 0, c.stream, A[r]->n_local, W[r].r0, W[r].q, (const double *)nullptr, (const double *)nullptr,
+                         W[r].slab1, done[r], nt[r]);
+    MK_D(reduce2([&](int r) { return W[r].slab1; }));                                    // <r0,q>
+    for (int r = 0; r < R; r++)
+      hipLaunchKernelGGL(bicg_step1_kernel, dim3(vb[r]), block, 0, c.stream, A[r]->n_local, W[r].p, W[r].q, x[r]->d, W[r].r, W[r].buf, 1, W[r].state,
+                         nt[r], it & 1);
+    MK_D(dist_spmv(R, A, rv.data(), sv.data(), 1.0, 0.0, done.data()));                  // s = A r
+    for (int r = 0; r < R; r++)
+      hipLaunchKernelGGL(dot2_kernel, dim3(vb[r]), block, 0, c.stream, A[r]->n_local, W[r].r, W[r].s, W[r].s, W[r].s, W[r].slab2, done[r], nt[r]);
+    MK_D(reduce2([&](int r) { return W[r].slab2; }));                                    // <r,s>, <s,s>
+    for (int r = 0; r < R; r++)
+      hipLaunchKernelGGL(bicg_step2_kernel, dim3(vb[r]), block, 0, c.stream, A[r]->n_local, W[r].s, W[r].r0, x[r]->d, W[r].r, W[r].buf, 1, 1,
+                         W[r].slab3, W[r].state, nt[r]);
+    MK_D(reduce2([&](int r) { return W[r].slab3; }));                                    // <r0,r>, <r,r> of the recursive residual
+    for (int r = 0; r < R; r++)
+      hipLaunchKernelGGL(bicg_norm_kernel, dim3(1), block, 0, c.stream, W[r].buf + 1, 1, W[r].state, W[r].norms);
+    // only when the recursive residual passed: r = b - A x and its two dots (slab3 keeps step 2's partials otherwise,
+    // and the fold + all-reduce below gives the same two values again: the host cannot know which it is without a wait)
+    for (int r = 0; r < R; r++)
+      if (A[r]->n_local) hipLaunchKernelGGL(copy_unless_kernel, dim3(vb[r]), dim3(256), 0, c.stream, W[r].r, b[r]->d, A[r]->n_local, skip[r]);
+    MK_D(dist_spmv(R, A, xv.data(), rv.data(), -1.0, 1.0, skip.data()));
+    for (int r = 0; r < R; r++)
+      hipLaunchKernelGGL(dot2_kernel, dim3(vb[r]), block, 0, c.stream, A[r]->n_local, W[r].r0, W[r].r, W[r].r, W[r].r, W[r].slab3, skip[r], nt[r]);
+    MK_D(reduce2([&](int r) { return W[r].slab3; }));
+    for (int r = 0; r < R; r++)
+      hipLaunchKernelGGL(bicg_step3_kernel, dim3(vb[r]), block, 0, c.stream, A[r]->n_local, W[r].r, W[r].q, W[r].p, W[r].buf, 1, 1, W[r].state, nt[r],
+                         it & 1);
+    if ((it + 1) % S0->check_every == 0) {
+      MK_DH(hipMemcpyAsync(&hst[0], W[0].state, sizeof(BicgState), hipMemcpyDeviceToHost, c.stream));
+      MK_DH(hipStreamSynchronize(c.stream));
+      if (hst[0].done != 0) stop = true;   // the same on every rank
+    }
+  }
+  MK_DH(hipGetLastError());
+  MK_DH(hipMemcpyAsync(&hst[0], W[0].state, sizeof(BicgState), hipMemcpyDeviceToHost, c.stream));
+  MK_DH(hipDeviceSynchronize());
+  for (int r = 0; r < R; r++) {
+    mk_bicgstab *S = solvers[r];
+    S->iterations = hst[0].iter;
+    S->converged = hst[0].converged;
+    S->breakdown = hst[0].breakdown;
+    S->rel_res_norm = hst[0].b_norm > 0.0 ? hst[0].r_norm / hst[0].b_norm : hst[0].r_norm;
+    if (want_norms) {   // the history goes to the solver object: mk_bicgstab_get_residual_history reads it there
+      dev_free(S->norms);
+      S->norms = W[r].norms;
+      S->norms_cap = S0->max_iter + 1;
+      W[r].norms = nullptr;
+    }
+  }
+  if (S0->print_level > 1 && (!A[0]->comm || A[0]->rank == 0))
+    printf("BiCGSTAB: %lld iterations, relative residual %e%s\n", S0->iterations, S0->rel_res_norm, S0->converged ? "" : " (not converged)");
+  cleanup();
+#undef MK_D
+#undef MK_DH
+  return MK_OK;
 }
 
 int mk_bicgstab_destroy(mk_bicgstab *S) {

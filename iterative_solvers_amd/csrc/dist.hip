@@ -28,8 +28,7 @@
 #include <cfloat>
 
 #include "krylov_kernels.h"
-
-struct mk_dist_matrix;
+#include "dist_internal.h"
 
 namespace mk {
 
@@ -87,39 +86,6 @@ static int load_rccl() {
 struct LocalWorld;
 
 }  // namespace mk
-
-struct mk_comm {
-  int nranks = 1, rank = 0;
-  bool local = false;
-  mk::LocalWorld *world = nullptr;
-  ncclComm_t coll = nullptr, p2p = nullptr;
-  hipStream_t comm_stream = nullptr;
-  hipEvent_t ev_ready = nullptr, ev_halo = nullptr;
-  // matrices created on this communicator; mk_comm_destroy() on a communicator that still has users only marks it, the
-  // last matrix to go tears it down (a host language's finaliser order is not ours to choose)
-  int users = 0;
-  bool dead = false;
-};
-
-struct mk_dist_matrix {
-  mk_comm *comm = nullptr;
-  int nranks = 1, rank = 0;
-  int64_t n_global = 0, row_begin = 0, row_end = 0, n_local = 0, n_ghost = 0;
-  std::vector<int64_t> row_start;
-  mk_matrix diag;              // n_local x n_local, local column ids
-  mk_matrix offd;              // n_offd_rows x n_ghost (compressed rows)
-  int *offd_rows = nullptr;    // local row of each offd row
-  int n_offd_rows = 0;
-  int gap0 = 0, gap1 = 0;      // the longest run of local rows [gap0, gap1) that touch no ghost (a z-slab: all but its end planes)
-  int offd_lanes = 1;
-  int *ghost_global = nullptr; // device, sorted global ids of the ghosts
-  std::vector<int> h_ghost;
-  std::vector<int> recv_cnt, recv_off, send_cnt, send_off;
-  int n_send = 0;
-  int *send_idx = nullptr;     // device: local rows to pack, grouped by destination
-  double *sendbuf = nullptr;
-  bool plan_ready = false;
-};
 
 namespace mk {
 
@@ -520,7 +486,7 @@ static int halo_mark(mk_dist_matrix *D) {
   return MK_OK;
 }
 
-static int all_reduce(int R, mk_dist_matrix **A, double **bufs, int count) {
+int dist_all_reduce(int R, mk_dist_matrix **A, double **bufs, int count) {
   Context &c = ctx();
   if (A[0]->comm == nullptr) return MK_OK;
   if (A[0]->comm->local) {
@@ -606,6 +572,16 @@ struct DistWork {
     dev_free(r); dev_free(p); dev_free(s); dev_free(slab1); dev_free(slab2); dev_free(buf); dev_free(state); dev_free(norms);
   }
 };
+
+int dist_spmv(int R, mk_dist_matrix **A, double **x, double **y, double alpha, double beta, const int *const *skip) {
+  MK_TRY(halo_exchange(R, A, x, true));
+  for (int r = 0; r < R; r++) MK_TRY(launch_spmv(&A[r]->diag, alpha, x[r], beta, y[r], skip ? skip[r] : nullptr));
+  for (int r = 0; r < R; r++) {
+    MK_TRY(halo_wait(A[r], true));
+    MK_TRY(launch_offd<false>(A[r], x[r], y[r], alpha, nullptr, skip ? skip[r] : nullptr, nullptr));
+  }
+  return MK_OK;
+}
 
 }  // namespace mk
 
@@ -852,7 +828,9 @@ int mk_dist_vector_create(const mk_dist_matrix *D, mk_vector **v) {
   return MK_OK;
 }
 
-static int check_ranks(const char *who, int R, mk_dist_matrix **A) {
+}  // extern "C"
+
+int mk::dist_check_ranks(const char *who, int R, mk_dist_matrix **A) {
   if (R < 1 || !A) return fail(MK_ERR_INVALID, "%s: bad argument", who);
   for (int r = 0; r < R; r++) {
     if (!A[r]) return fail(MK_ERR_INVALID, "%s: null matrix", who);
@@ -868,10 +846,12 @@ static int check_ranks(const char *who, int R, mk_dist_matrix **A) {
   return MK_OK;
 }
 
+extern "C" {
+
 // y = A x on every rank this process drives (collective over RCCL)
 int mk_dist_spmv(int R, mk_dist_matrix **A, mk_vector **x, mk_vector **y) {
   MK_REQUIRE_INIT();
-  MK_TRY(check_ranks("mk_dist_spmv", R, A));
+  MK_TRY(dist_check_ranks("mk_dist_spmv", R, A));
   if (!x || !y) return fail(MK_ERR_INVALID, "mk_dist_spmv: null argument");
   std::vector<double *> xv(R);
   for (int r = 0; r < R; r++) {
@@ -879,19 +859,15 @@ int mk_dist_spmv(int R, mk_dist_matrix **A, mk_vector **x, mk_vector **y) {
       return fail(MK_ERR_INVALID, "mk_dist_spmv: vectors must come from mk_dist_vector_create of the same matrix");
     xv[r] = x[r]->d;
   }
-  MK_TRY(halo_exchange(R, A, xv.data(), true));
-  for (int r = 0; r < R; r++) MK_TRY(launch_spmv(&A[r]->diag, 1.0, x[r]->d, 0.0, y[r]->d));
-  for (int r = 0; r < R; r++) {
-    MK_TRY(halo_wait(A[r], true));
-    MK_TRY(launch_offd<false>(A[r], x[r]->d, y[r]->d, 1.0, nullptr, nullptr, nullptr));
-  }
-  return MK_OK;
+  std::vector<double *> yv(R);
+  for (int r = 0; r < R; r++) yv[r] = y[r]->d;
+  return dist_spmv(R, A, xv.data(), yv.data(), 1.0, 0.0, nullptr);
 }
 
 // HYPRE_ParCSRPCGSetup + Solve over the row blocks (solvers.c:747-754 with num_procs > 1)
 int mk_dist_pcg_solve(int R, mk_pcg **solvers, mk_dist_matrix **A, mk_vector **b, mk_vector **x) {
   MK_REQUIRE_INIT();
-  MK_TRY(check_ranks("mk_dist_pcg_solve", R, A));
+  MK_TRY(dist_check_ranks("mk_dist_pcg_solve", R, A));
   if (!solvers || !b || !x) return fail(MK_ERR_INVALID, "mk_dist_pcg_solve: null argument");
   Context &c = ctx();
   mk_pcg *S0 = solvers[0];
@@ -955,7 +931,7 @@ int mk_dist_pcg_solve(int R, mk_pcg **solvers, mk_dist_matrix **A, mk_vector **b
     hipLaunchKernelGGL(pcg_init_vectors_kernel, dim3(vb[r]), dim3(kVecThreads), 0, c.stream, nl, b[r]->d, W[r].r, dinv, W[r].p, two_norm, W[r].slab2);
     hipLaunchKernelGGL((finalize_slab_kernel<3>), dim3(1), dim3(kVecThreads), 0, c.stream, W[r].slab2, vb[r], W[r].buf);
   }
-  MK_D(all_reduce(R, A, bufs.data(), 3));
+  MK_D(dist_all_reduce(R, A, bufs.data(), 3));
   for (int r = 0; r < R; r++)
     hipLaunchKernelGGL(pcg_init_scalars_kernel, dim3(1), dim3(kVecThreads), 0, c.stream, W[r].buf, 1, 1, S0->tol, two_norm, W[r].state, W[r].norms);
   MK_DH(hipMemcpyAsync(&hst[0], W[0].state, sizeof(PcgState), hipMemcpyDeviceToHost, c.stream));
@@ -1012,7 +988,7 @@ int mk_dist_pcg_solve(int R, mk_pcg **solvers, mk_dist_matrix **A, mk_vector **b
       else if (!fusedv[r]) MK_D(launch_offd<true>(A[r], pv[r], W[r].s, 1.0, W[r].slab1 + nb1[r], &W[r].state->done, &nb2[r], kSlabStride - nb1[r]));
       hipLaunchKernelGGL((finalize_slab_kernel<2>), dim3(1), dim3(kVecThreads), 0, c.stream, W[r].slab1, nb1[r] + nb2[r], W[r].buf);
     }
-    MK_D(all_reduce(R, A, bufs.data(), 2));                                       // <s,p>, <p,p>
+    MK_D(dist_all_reduce(R, A, bufs.data(), 2));                                       // <s,p>, <p,p>
     for (int r = 0; r < R; r++) {
       const int64_t nl = A[r]->n_local;
       double *buf3 = W[r].buf + 4;
@@ -1030,7 +1006,7 @@ int mk_dist_pcg_solve(int R, mk_pcg **solvers, mk_dist_matrix **A, mk_vector **b
       hipLaunchKernelGGL((finalize_slab_kernel<3>), dim3(1), dim3(kVecThreads), 0, c.stream, W[r].slab2, nbk2, buf3);
       bufs[r] = buf3;
     }
-    MK_D(all_reduce(R, A, bufs.data(), 3));                                       // <r,z>, <r,r>, <x,x>
+    MK_D(dist_all_reduce(R, A, bufs.data(), 3));                                       // <r,z>, <r,r>, <x,x>
     for (int r = 0; r < R; r++) {
       const int64_t nl = A[r]->n_local;
       bufs[r] = W[r].buf;
@@ -1085,7 +1061,7 @@ int mk_dist_pcg_solve(int R, mk_pcg **solvers, mk_dist_matrix **A, mk_vector **b
 // where it is tested (every check_every).
 int mk_dist_jacobi_solve(int R, mk_jacobi **solvers, mk_dist_matrix **A, mk_vector **b, mk_vector **x) {
   MK_REQUIRE_INIT();
-  MK_TRY(check_ranks("mk_dist_jacobi_solve", R, A));
+  MK_TRY(dist_check_ranks("mk_dist_jacobi_solve", R, A));
   if (!solvers || !b || !x) return fail(MK_ERR_INVALID, "mk_dist_jacobi_solve: null argument");
   static const int no_gap = getenv("MK_NO_EXTRA_GAP") ? atoi(getenv("MK_NO_EXTRA_GAP")) : 0;   // A/B: the sweep reads the whole off-rank vector
   Context &c = ctx();
@@ -1152,7 +1128,7 @@ int mk_dist_jacobi_solve(int R, mk_jacobi **solvers, mk_dist_matrix **A, mk_vect
     hipLaunchKernelGGL(dot_self_kernel, dim3(vb[r]), dim3(256), 0, c.stream, A[r]->n_local, b[r]->d, W[r].slab);
     hipLaunchKernelGGL((finalize_slab_kernel<1>), dim3(1), dim3(kVecThreads), 0, c.stream, W[r].slab, vb[r], W[r].buf);
   }
-  MK_D(all_reduce(R, A, bufs.data(), 1));
+  MK_D(dist_all_reduce(R, A, bufs.data(), 1));
   for (int r = 0; r < R; r++) hipLaunchKernelGGL(jacobi_init_kernel, dim3(1), dim3(256), 0, c.stream, W[r].buf, 1, 1, S0->tol, W[r].state);
   MK_DH(hipMemcpyAsync(hst, W[0].state, sizeof(JacobiState), hipMemcpyDeviceToHost, c.stream));
   MK_DH(hipStreamSynchronize(c.stream));
@@ -1223,7 +1199,7 @@ int mk_dist_jacobi_solve(int R, mk_jacobi **solvers, mk_dist_matrix **A, mk_vect
     if (k % S0->check_every == 0 || last) {
       for (int r = 0; r < R; r++)
         hipLaunchKernelGGL((finalize_slab_kernel<1>), dim3(1), dim3(kVecThreads), 0, c.stream, W[r].slab, blocks[r], W[r].buf);
-      MK_D(all_reduce(R, A, bufs.data(), 1));
+      MK_D(dist_all_reduce(R, A, bufs.data(), 1));
       for (int r = 0; r < R; r++)
         hipLaunchKernelGGL(jacobi_check_kernel, dim3(1), dim3(256), 0, c.stream, W[r].buf, 1, 1, k, W[r].state);
       checks++;

@@ -18,6 +18,7 @@
 #include <cmath>
 #include <vector>
 
+#include "dist_internal.h"
 #include "krylov_kernels.h"
 
 namespace mk {
@@ -42,10 +43,10 @@ static __global__ __launch_bounds__(kVecThreads) void gmres_dot2_kernel(int64_t 
 }
 
 // out[0..1] = sqrt of the two reduced components
-static __global__ __launch_bounds__(kVecThreads) void gmres_norm2_kernel(const double *slab, int nblocks, double *out) {
+static __global__ __launch_bounds__(kVecThreads) void gmres_norm2_kernel(const double *slab, int nblocks, int stride, double *out) {
   __shared__ double smem[2 * (kVecThreads / 64)];
   double v[2];
-  reduce_slab<2, kVecThreads>(slab, nblocks, kSlabStride, v, smem);
+  reduce_slab<2, kVecThreads>(slab, nblocks, stride, v, smem);
   if (threadIdx.x == 0) { out[0] = sqrt(v[0]); out[1] = sqrt(v[1]); }
 }
 
@@ -227,7 +228,7 @@ int mk_gmres_solve(mk_gmres *S, const mk_matrix *A, const mk_vector *b, mk_vecto
     hipLaunchKernelGGL(copy_kernel, grid, dim3(256), 0, c.stream, dst, b->d, n);
     MK_TRY(launch_spmv(A, -1.0, x->d, 1.0, dst));
     hipLaunchKernelGGL(gmres_dot2_kernel, grid, block, 0, c.stream, n, dst, b->d, S->slab1);
-    hipLaunchKernelGGL(gmres_norm2_kernel, dim3(1), block, 0, c.stream, S->slab1, vb, S->hcol);
+    hipLaunchKernelGGL(gmres_norm2_kernel, dim3(1), block, 0, c.stream, S->slab1, vb, kSlabStride, S->hcol);
     MK_HIP(hipMemcpyAsync(hpin, S->hcol, 2 * sizeof(double), hipMemcpyDeviceToHost, c.stream));
     MK_HIP(hipStreamSynchronize(c.stream));
     *r_norm = hpin[0];
@@ -341,6 +342,178 @@ int mk_gmres_get_residual_history(const mk_gmres *S, double *norms, int capacity
   const int count = (int)std::min<size_t>(S->norms.size(), (size_t)capacity);
   for (int k = 0; k < count; k++) norms[k] = S->norms[k];
   return count;
+}
+
+// ---------------------------------------------------------------------------- row blocks
+// HYPRE_ParCSRGMRESSetup + Solve over the row blocks (solvers.c:1183-1245 with num_procs > 1).  The loop of mk_gmres_solve
+// with every product done by dist_spmv and every inner product of the modified Gram-Schmidt chain all-reduced before the
+// next link reads it (hypre_ParKrylovInnerProd is an MPI_Allreduce: i + 1 of them in iteration i of a cycle, the same
+// count here).  The Hessenberg column is the same on every rank (all-reduced values only), so every rank's host takes the
+// same decisions from its own copy; in a local world rank 0's copy drives all of them.
+int mk_dist_gmres_solve(int R, mk_gmres **solvers, mk_dist_matrix **A, mk_vector **b, mk_vector **x) {
+  MK_REQUIRE_INIT();
+  MK_TRY(dist_check_ranks("mk_dist_gmres_solve", R, A));
+  if (!solvers || !b || !x) return fail(MK_ERR_INVALID, "mk_dist_gmres_solve: null argument");
+  Context &c = ctx();
+  mk_gmres *S0 = solvers[0];
+  for (int r = 0; r < R; r++) {
+    if (!solvers[r] || !b[r] || !x[r]) return fail(MK_ERR_INVALID, "mk_dist_gmres_solve: null argument");
+    if (b[r]->n != A[r]->n_local || x[r]->n != A[r]->n_local || x[r]->cap < A[r]->n_local + A[r]->n_ghost)
+      return fail(MK_ERR_INVALID, "mk_dist_gmres_solve: vectors must come from mk_dist_vector_create of the same matrix");
+    if (solvers[r]->max_iter != S0->max_iter || solvers[r]->tol != S0->tol || solvers[r]->k_dim != S0->k_dim)
+      return fail(MK_ERR_INVALID, "mk_dist_gmres_solve: ranks disagree on solver settings");
+  }
+  const int k_dim = S0->k_dim;
+  const bool want_norms = S0->logging > 0 || S0->print_level > 0;
+  struct Work {
+    double *basis = nullptr, *w = nullptr, *slab1 = nullptr, *slab2 = nullptr, *hcol = nullptr, *buf = nullptr;
+    int64_t ld = 0;
+    void release() { dev_free(basis); dev_free(w); dev_free(slab1); dev_free(slab2); dev_free(hcol); dev_free(buf); }
+  };
+  std::vector<Work> W(R);
+  std::vector<double *> xv(R), bufs(R), va(R), vo(R);
+  std::vector<int> vb(R), nt(R);
+  std::vector<int64_t> nl(R);
+  int rc = MK_OK;
+  auto cleanup = [&]() { (void)hipDeviceSynchronize(); for (auto &w : W) w.release(); };
+#define MK_D(expr) do { rc = (expr); if (rc != MK_OK) { cleanup(); return rc; } } while (0)
+#define MK_DH(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return fail(MK_ERR_HIP, "%s -> %s", #expr, hipGetErrorString(e_)); } } while (0)
+  for (int r = 0; r < R; r++) {
+    nl[r] = A[r]->n_local;
+    W[r].ld = (nl[r] + A[r]->n_ghost + 31) & ~(int64_t)31;   // every basis vector is the operand of a product: ghosts behind the owned rows
+    W[r].ld = std::max<int64_t>(W[r].ld, 32);
+    MK_D(dev_alloc(&W[r].basis, (size_t)W[r].ld * (size_t)(k_dim + 1)));
+    MK_D(dev_alloc(&W[r].w, (size_t)std::max<int64_t>(nl[r], 1)));
+    MK_D(dev_alloc(&W[r].slab1, (size_t)2 * kSlabStride));
+    MK_D(dev_alloc(&W[r].slab2, (size_t)2 * kSlabStride));
+    MK_D(dev_alloc(&W[r].hcol, (size_t)kGmresMaxK + 2));
+    MK_D(dev_alloc(&W[r].buf, 8));
+    MK_D(analyse_matrix(&A[r]->diag));
+    xv[r] = x[r]->d; bufs[r] = W[r].buf;
+    vb[r] = vec_blocks(nl[r]);
+    nt[r] = (int)nt_rows(nl[r]);
+    solvers[r]->iterations = 0; solvers[r]->rel_res_norm = 0.0; solvers[r]->converged = 0;
+    solvers[r]->norms.clear();
+  }
+  const dim3 block(kVecThreads);
+  double *hpin = static_cast<double *>(c.pinned);
+  auto P = [&](int r, int j) { return W[r].basis + (int64_t)j * W[r].ld; };
+  const double epsmac = 1.e-16;
+  std::vector<double> rs(k_dim + 1, 0.0), cs(k_dim, 0.0), sn(k_dim, 0.0), hh((size_t)(k_dim + 1) * k_dim, 0.0), norms;
+  auto HH = [&](int a, int bb) -> double & { return hh[(size_t)a * k_dim + bb]; };
+  auto each = [&](auto f) { for (int r = 0; r < R; r++) f(r); };
+
+  // dst = b - A x on every rank (dst: basis vector 0, or w), ||dst|| and ||b|| all-reduced and brought to the host
+  auto residual_into = [&](bool into_w, double *r_norm, double *b_norm) -> int {
+    each([&](int r) {
+      vo[r] = into_w ? W[r].w : P(r, 0);
+      if (nl[r]) hipLaunchKernelGGL(copy_kernel, dim3(vb[r]), dim3(256), 0, c.stream, vo[r], b[r]->d, nl[r]);
+    });
+    MK_TRY(dist_spmv(R, A, xv.data(), vo.data(), -1.0, 1.0, nullptr));
+    each([&](int r) {
+      hipLaunchKernelGGL(gmres_dot2_kernel, dim3(vb[r]), block, 0, c.stream, nl[r], vo[r], b[r]->d, W[r].slab1);
+      hipLaunchKernelGGL((finalize_slab_kernel<2>), dim3(1), block, 0, c.stream, W[r].slab1, vb[r], W[r].buf);
+    });
+    MK_TRY(dist_all_reduce(R, A, bufs.data(), 2));
+    each([&](int r) { hipLaunchKernelGGL(gmres_norm2_kernel, dim3(1), block, 0, c.stream, W[r].buf, 1, 1, W[r].hcol); });
+    MK_HIP(hipMemcpyAsync(hpin, W[0].hcol, 2 * sizeof(double), hipMemcpyDeviceToHost, c.stream));
+    MK_HIP(hipStreamSynchronize(c.stream));
+    *r_norm = hpin[0];
+    if (b_norm) *b_norm = hpin[1];
+    return MK_OK;
+  };
+
+  double r_norm = 0.0, b_norm = 0.0;
+  MK_D(residual_into(false, &r_norm, &b_norm));
+  if (want_norms) norms.push_back(r_norm);
+  const double den_norm = b_norm > 0.0 ? b_norm : r_norm;
+  const double epsilon = S0->tol * den_norm;
+  long long iter = 0;
+  int converged = 0;
+  while (iter < S0->max_iter) {
+    rs[0] = r_norm;
+    if (r_norm == 0.0) break;
+    if (r_norm <= epsilon) {
+      MK_D(residual_into(true, &r_norm, nullptr));
+      if (r_norm <= epsilon) { converged = 1; break; }
+    }
+    each([&](int r) { if (nl[r]) hipLaunchKernelGGL(gmres_scale_kernel, dim3(vb[r]), dim3(256), 0, c.stream, nl[r], P(r, 0), 1.0 / r_norm); });
+    int i = 0;
+    while (i < k_dim && iter < S0->max_iter) {
+      i++; iter++;
+      each([&](int r) { va[r] = P(r, i - 1); vo[r] = P(r, i); });
+      MK_D(dist_spmv(R, A, va.data(), vo.data(), 1.0, 0.0, nullptr));
+      // the chain: link j reads the all-reduced <p[j-1], p[i]> from buf, its own partials go to slab1, folded and all-reduced
+      for (int j = 0; j <= i; j++) {
+        each([&](int r) {
+          hipLaunchKernelGGL(gmres_mgs_kernel, dim3(vb[r]), block, 0, c.stream, nl[r], P(r, i), j > 0 ? P(r, j - 1) : (const double *)nullptr,
+                             j < i ? P(r, j) : (const double *)nullptr, W[r].buf, 1, W[r].slab1, W[r].hcol, j - 1, nt[r]);
+          hipLaunchKernelGGL((finalize_slab_kernel<1>), dim3(1), block, 0, c.stream, W[r].slab1, vb[r], W[r].buf);
+        });
+        MK_D(dist_all_reduce(R, A, bufs.data(), 1));
+      }
+      each([&](int r) { hipLaunchKernelGGL(gmres_hnorm_kernel, dim3(1), block, 0, c.stream, W[r].buf, 1, W[r].hcol, i); });
+      MK_DH(hipMemcpyAsync(hpin, W[0].hcol, (size_t)(i + 1) * sizeof(double), hipMemcpyDeviceToHost, c.stream));
+      MK_DH(hipStreamSynchronize(c.stream));
+      for (int j = 0; j <= i; j++) HH(j, i - 1) = hpin[j];
+      double t = HH(i, i - 1);
+      if (t != 0.0) each([&](int r) { if (nl[r]) hipLaunchKernelGGL(gmres_scale_kernel, dim3(vb[r]), dim3(256), 0, c.stream, nl[r], P(r, i), 1.0 / t); });
+      for (int j = 1; j < i; j++) {
+        t = HH(j - 1, i - 1);
+        HH(j - 1, i - 1) = sn[j - 1] * HH(j, i - 1) + cs[j - 1] * t;
+        HH(j, i - 1) = -sn[j - 1] * t + cs[j - 1] * HH(j, i - 1);
+      }
+      t = HH(i, i - 1) * HH(i, i - 1);
+      t += HH(i - 1, i - 1) * HH(i - 1, i - 1);
+      double gamma = sqrt(t);
+      if (gamma == 0.0) gamma = epsmac;
+      cs[i - 1] = HH(i - 1, i - 1) / gamma;
+      sn[i - 1] = HH(i, i - 1) / gamma;
+      rs[i] = -HH(i, i - 1) * rs[i - 1];
+      rs[i] /= gamma;
+      rs[i - 1] = cs[i - 1] * rs[i - 1];
+      HH(i - 1, i - 1) = sn[i - 1] * HH(i, i - 1) + cs[i - 1] * HH(i - 1, i - 1);
+      r_norm = fabs(rs[i]);
+      if (want_norms) norms.push_back(r_norm);
+      if (r_norm <= epsilon) break;
+    }
+    rs[i - 1] = rs[i - 1] / HH(i - 1, i - 1);
+    for (int k = i - 2; k >= 0; k--) {
+      double t = 0.0;
+      for (int j = k + 1; j < i; j++) t -= HH(k, j) * rs[j];
+      t += rs[k];
+      rs[k] = t / HH(k, k);
+    }
+    GmresCoef coef;
+    for (int j = 0; j <= i; j++) coef.v[j] = rs[j];
+    each([&](int r) { if (nl[r]) hipLaunchKernelGGL(gmres_update_x_kernel, dim3(vb[r]), dim3(256), 0, c.stream, nl[r], W[r].basis, W[r].ld, i, coef, x[r]->d); });
+    if (r_norm <= epsilon) {
+      MK_D(residual_into(true, &r_norm, nullptr));
+      if (r_norm <= epsilon) { converged = 1; break; }
+      each([&](int r) { if (nl[r]) hipLaunchKernelGGL(copy_kernel, dim3(vb[r]), dim3(256), 0, c.stream, P(r, 0), W[r].w, nl[r]); });
+      continue;
+    }
+    for (int j = i; j > 0; j--) {
+      rs[j - 1] = -sn[j - 1] * rs[j];
+      rs[j] = cs[j - 1] * rs[j];
+    }
+    for (int j = 0; j <= i; j++) coef.v[j] = rs[j];
+    each([&](int r) { if (nl[r]) hipLaunchKernelGGL(gmres_residual_kernel, dim3(vb[r]), dim3(256), 0, c.stream, nl[r], W[r].basis, W[r].ld, i, coef); });
+  }
+  MK_DH(hipGetLastError());
+  MK_DH(hipDeviceSynchronize());
+  for (int r = 0; r < R; r++) {
+    solvers[r]->iterations = iter;
+    solvers[r]->converged = converged;
+    solvers[r]->rel_res_norm = b_norm > 0.0 ? r_norm / b_norm : r_norm;
+    solvers[r]->norms = norms;
+  }
+  if (S0->print_level > 1 && (!A[0]->comm || A[0]->rank == 0))
+    printf("GMRES(%d): %lld iterations, relative residual %e%s\n", k_dim, S0->iterations, S0->rel_res_norm, S0->converged ? "" : " (not converged)");
+  cleanup();
+#undef MK_D
+#undef MK_DH
+  return MK_OK;
 }
 
 int mk_gmres_destroy(mk_gmres *S) {
