@@ -128,10 +128,6 @@ static int exchange_comm_id(const char *path, int rank, unsigned char *id256) {
  * mk_partition_rows gives it, and the ranks solve together through mk_dist_*. */
 static int run_distributed(const char *mtx, const char *bfile, const char *xfile, const char *id_file, int np, int rank,
                            int solver_id, int maxit, double tol, int prnt_info, int niter, int print_system) {
-  if (solver_id != 50 && solver_id != 51 && solver_id != 70) {
-    fprintf(stderr, "solver %d runs on one GPU only; the row-block path serves 50, 51 and 70\n", solver_id);
-    return 1;
-  }
   mk_comm *comm = NULL;
   unsigned char id[256];
   if (np > 1 && !id_file) { fprintf(stderr, "-np %d needs -id_file <path on a directory all ranks see>\n", np); return 1; }
@@ -202,8 +198,53 @@ static int run_distributed(const char *mtx, const char *bfile, const char *xfile
 
   long long num_iterations = 0;
   double final_res_norm = 0.0, walltime = 0.0;
-  const char *label = solver_id == 70 ? "Jacobi" : "PCG";
-  if (solver_id == 70) {
+  const char *label = solver_id == 70 ? "Jacobi" : solver_id == 6 ? "ParCSRBiCGSTABC" : solver_id == 12 ? "GMRES" : solver_id == 40 ? "CGNR" : "PCG";
+  if (solver_id == 6) {
+    mk_bicgstab *solver = NULL;
+    CK(mk_bicgstab_create(&solver));                                    /* :524 */
+    CK(mk_bicgstab_set_print_level(solver, rank == 0 ? prnt_info : 0)); /* :527 */
+    CK(mk_bicgstab_set_logging(solver, 1));                             /* :529 */
+    CK(mk_bicgstab_set_tol(solver, tol));                               /* :532 */
+    CK(mk_bicgstab_set_max_iter(solver, maxit));                        /* :533 */
+    CK(mk_synchronize());
+    double t = -now_s();                                                /* :540 */
+    for (int i = 0; i < niter; i++) CK(mk_dist_bicgstab_solve(1, &solver, &A, &b, &x));   /* :536-542 */
+    CK(mk_synchronize());
+    walltime = t + now_s();
+    CK(mk_bicgstab_get_num_iterations(solver, &num_iterations));        /* :553 */
+    CK(mk_bicgstab_get_final_relative_residual_norm(solver, &final_res_norm)); /* :554 */
+    CK(mk_bicgstab_destroy(solver));                                    /* :563 */
+  } else if (solver_id == 12) {
+    mk_gmres *solver = NULL;
+    CK(mk_gmres_create(&solver));                                       /* :1189 */
+    CK(mk_gmres_set_max_iter(solver, maxit));                           /* :1191 */
+    CK(mk_gmres_set_k_dim(solver, 30));                                 /* :1192 */
+    CK(mk_gmres_set_tol(solver, tol));                                  /* :1193 */
+    CK(mk_gmres_set_print_level(solver, rank == 0 ? prnt_info : 0));    /* :1195 */
+    CK(mk_gmres_set_logging(solver, 1));                                /* :1196 */
+    CK(mk_synchronize());
+    double t = -now_s();                                                /* :1213 */
+    for (int i = 0; i < niter; i++) CK(mk_dist_gmres_solve(1, &solver, &A, &b, &x));      /* :1200-1217 */
+    CK(mk_synchronize());
+    walltime = t + now_s();
+    CK(mk_gmres_get_num_iterations(solver, &num_iterations));           /* :1231 */
+    CK(mk_gmres_get_final_relative_residual_norm(solver, &final_res_norm)); /* :1232 */
+    CK(mk_gmres_destroy(solver));
+  } else if (solver_id == 40) {
+    mk_cgnr *solver = NULL;
+    CK(mk_cgnr_create(&solver));                                        /* :869 */
+    CK(mk_cgnr_set_max_iter(solver, maxit));                            /* :872 */
+    CK(mk_cgnr_set_tol(solver, tol));                                   /* :873 */
+    CK(mk_cgnr_set_logging(solver, 1));                                 /* :874 */
+    CK(mk_synchronize());
+    double t = -now_s();                                                /* :882 */
+    for (int i = 0; i < niter; i++) CK(mk_dist_cgnr_solve(1, &solver, &A, &b, &x));       /* :877-884 */
+    CK(mk_synchronize());
+    walltime = t + now_s();
+    CK(mk_cgnr_get_num_iterations(solver, &num_iterations));            /* :895 */
+    CK(mk_cgnr_get_final_relative_residual_norm(solver, &final_res_norm)); /* :896 */
+    CK(mk_cgnr_destroy(solver));                                        /* :905 */
+  } else if (solver_id == 70) {
     mk_jacobi *solver = NULL;
     CK(mk_jacobi_create(&solver));
     CK(mk_jacobi_set_max_iter(solver, maxit));

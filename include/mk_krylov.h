@@ -329,6 +329,9 @@ int mk_dist_jacobi_solve(int nranks_here, mk_jacobi **solvers, mk_dist_matrix **
  * mk_bicgstab_* / mk_gmres_* setters and getters */
 int mk_dist_bicgstab_solve(int nranks_here, mk_bicgstab **solvers, mk_dist_matrix **A, mk_vector **b, mk_vector **x);
 int mk_dist_gmres_solve(int nranks_here, mk_gmres **solvers, mk_dist_matrix **A, mk_vector **b, mk_vector **x);
+/* HYPRE_ParCSRCGNRSetup + Solve (solvers.c:864-906) on the distributed operator: A^T r through the reverse exchange (the
+ * transposed blocks are built at the first call and live with the matrix) */
+int mk_dist_cgnr_solve(int nranks_here, mk_cgnr **solvers, mk_dist_matrix **A, mk_vector **b, mk_vector **x);
 
 /* ---- exchange planning, host only (no GPU): the host half of the ParCSR communication package that
  *      HYPRE_IJMatrixAssemble builds (solvers.c:362); mk_dist_matrix_create runs exactly these -------------- */

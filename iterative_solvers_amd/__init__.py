@@ -76,7 +76,7 @@ EXPORTS = [
     "mk_partition_rows", "mk_halo_check_row_start", "mk_halo_ghost_columns", "mk_halo_plan_recv", "mk_halo_plan_send",
     "mk_comm_get_unique_id", "mk_comm_create", "mk_comm_create_local", "mk_comm_self_test", "mk_comm_all_reduce_host", "mk_comm_destroy",
     "mk_dist_matrix_create", "mk_dist_matrix_destroy", "mk_dist_matrix_get_info", "mk_dist_matrix_get_diag_info", "mk_dist_matrix_set_spmv_kernel",
-    "mk_dist_vector_create", "mk_dist_spmv", "mk_dist_pcg_solve", "mk_dist_jacobi_solve", "mk_dist_bicgstab_solve", "mk_dist_gmres_solve",
+    "mk_dist_vector_create", "mk_dist_spmv", "mk_dist_pcg_solve", "mk_dist_jacobi_solve", "mk_dist_bicgstab_solve", "mk_dist_gmres_solve", "mk_dist_cgnr_solve",
 ]
 
 _lib = None

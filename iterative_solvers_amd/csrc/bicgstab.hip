@@ -619,11 +619,11 @@ static __global__ __launch_bounds__(kVecThreads) void cgnr_init_p_kernel(int64_t
   if (threadIdx.x == 0) slab[blockIdx.x] = v[0];
 }
 
-static __global__ __launch_bounds__(kVecThreads) void cgnr_init_scalars_kernel(const double *slab_bb_rr, const double *slab_tt, int nblocks,
+static __global__ __launch_bounds__(kVecThreads) void cgnr_init_scalars_kernel(const double *slab_bb_rr, const double *slab_tt, int nblocks, int stride,
                                                                                double tol, CgnrState *st, double *norms) {
   __shared__ double smem[2 * (kVecThreads / 64)];
   double v[2], g[1];
-  reduce_slab<2, kVecThreads>(slab_bb_rr, nblocks, kSlabStride, v, smem);
+  reduce_slab<2, kVecThreads>(slab_bb_rr, nblocks, stride, v, smem);
   reduce_slab<1, kVecThreads>(slab_tt, nblocks, kSlabStride, g, smem);
   if (threadIdx.x == 0) {
     CgnrState s;
@@ -824,7 +824,7 @@ int mk_cgnr_solve(mk_cgnr *S, const mk_matrix *A, const mk_vector *b, mk_vector 
   hipLaunchKernelGGL(cgnr_init_dots_kernel, grid, block, 0, c.stream, n, b->d, S->r, S->slab1);
   MK_TRY(launch_spmv(S->AT, 1.0, S->r, 0.0, S->t));
   hipLaunchKernelGGL(cgnr_init_p_kernel, grid, block, 0, c.stream, n, S->t, S->p, S->slab2);
-  hipLaunchKernelGGL(cgnr_init_scalars_kernel, dim3(1), block, 0, c.stream, S->slab1, S->slab2, vb, S->tol, S->state, S->norms);
+  hipLaunchKernelGGL(cgnr_init_scalars_kernel, dim3(1), block, 0, c.stream, S->slab1, S->slab2, vb, kSlabStride, S->tol, S->state, S->norms);
   MK_HIP(hipMemcpyAsync(&hst[0], S->state, sizeof(CgnrState), hipMemcpyDeviceToHost, c.stream));
   MK_HIP(hipStreamSynchronize(c.stream));
   if (hst[0].bi_prod == 0.0) {   // hypre: zero right-hand side -> x = b, no iterations
@@ -890,6 +890,148 @@ int mk_cgnr_get_residual_history(const mk_cgnr *S, double *norms, int capacity) 
     MK_HIP(hipStreamSynchronize(ctx().stream));
   }
   return count;
+}
+
+// ---------------------------------------------------------------------------- row blocks
+// HYPRE_ParCSRCGNRSetup + Solve over the row blocks (solvers.c:864-906 with num_procs > 1): the loop of mk_cgnr_solve with
+// q = A p behind a halo exchange, t = A^T r through the reverse exchange (dist_spmv_transpose: every rank's rows contribute
+// to rows of its neighbours, the contributions travel back along the plan) and four all-reduces per iteration.
+int mk_dist_cgnr_solve(int R, mk_cgnr **solvers, mk_dist_matrix **A, mk_vector **b, mk_vector **x) {
+  MK_REQUIRE_INIT();
+  MK_TRY(dist_check_ranks("mk_dist_cgnr_solve", R, A));
+  if (!solvers || !b || !x) return fail(MK_ERR_INVALID, "mk_dist_cgnr_solve: null argument");
+  Context &c = ctx();
+  mk_cgnr *S0 = solvers[0];
+  for (int r = 0; r < R; r++) {
+    if (!solvers[r] || !b[r] || !x[r]) return fail(MK_ERR_INVALID, "mk_dist_cgnr_solve: null argument");
+    if (b[r]->n != A[r]->n_local || x[r]->n != A[r]->n_local || x[r]->cap < A[r]->n_local + A[r]->n_ghost)
+      return fail(MK_ERR_INVALID, "mk_dist_cgnr_solve: vectors must come from mk_dist_vector_create of the same matrix");
+    if (solvers[r]->max_iter != S0->max_iter || solvers[r]->tol != S0->tol || solvers[r]->check_every != S0->check_every)
+      return fail(MK_ERR_INVALID, "mk_dist_cgnr_solve: ranks disagree on solver settings");
+  }
+  const bool want_norms = S0->logging > 0;
+  struct Work {
+    double *r = nullptr, *p = nullptr, *q = nullptr, *t = nullptr, *slab1 = nullptr, *slab2 = nullptr, *slab3 = nullptr, *buf = nullptr, *norms = nullptr;
+    CgnrState *state = nullptr;
+    void release() {
+      dev_free(r); dev_free(p); dev_free(q); dev_free(t); dev_free(slab1); dev_free(slab2); dev_free(slab3); dev_free(buf); dev_free(norms);
+      dev_free(state);
+    }
+  };
+  std::vector<Work> W(R);
+  std::vector<double *> pv(R), rv(R), qv(R), tv(R), xv(R), bufs(R);
+  std::vector<const int *> done(R), skip(R);
+  std::vector<int> vb(R), nt(R);
+  std::vector<int64_t> nl(R);
+  int rc = MK_OK;
+  auto cleanup = [&]() { (void)hipDeviceSynchronize(); for (auto &w : W) w.release(); };
+#define MK_D(expr) do { rc = (expr); if (rc != MK_OK) { cleanup(); return rc; } } while (0)
+#define MK_DH(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return fail(MK_ERR_HIP, "%s -> %s", #expr, hipGetErrorString(e_)); } } while (0)
+  for (int r = 0; r < R; r++) {
+    nl[r] = A[r]->n_local;
+    const size_t n1 = (size_t)std::max<int64_t>(nl[r], 1), ne = (size_t)std::max<int64_t>(nl[r] + A[r]->n_ghost, 1);
+    MK_D(dev_alloc(&W[r].r, n1));
+    MK_D(dev_alloc(&W[r].p, ne));    // operand of q = A p: ghosts behind the owned rows
+    MK_D(dev_alloc(&W[r].q, n1));
+    MK_D(dev_alloc(&W[r].t, n1));
+    MK_D(dev_alloc(&W[r].slab1, (size_t)2 * kSlabStride));
+    MK_D(dev_alloc(&W[r].slab2, (size_t)2 * kSlabStride));
+    MK_D(dev_alloc(&W[r].slab3, (size_t)2 * kSlabStride));
+    MK_D(dev_alloc(&W[r].buf, 8));
+    MK_D(dev_alloc(&W[r].state, 1));
+    if (want_norms) MK_D(dev_alloc(&W[r].norms, (size_t)S0->max_iter + 1));
+    MK_D(analyse_matrix(&A[r]->diag));
+    pv[r] = W[r].p; rv[r] = W[r].r; qv[r] = W[r].q; tv[r] = W[r].t; xv[r] = x[r]->d; bufs[r] = W[r].buf;
+    done[r] = &W[r].state->done; skip[r] = &W[r].state->skip_true;
+    vb[r] = vec_blocks(nl[r]);
+    nt[r] = (int)nt_rows(nl[r]);
+    solvers[r]->iterations = 0; solvers[r]->rel_res_norm = 0.0; solvers[r]->converged = 0;
+  }
+  const dim3 block(kVecThreads);
+  auto each = [&](auto f) { for (int r = 0; r < R; r++) f(r); };
+  auto fold1 = [&](int r, const double *slab, int at) {
+    hipLaunchKernelGGL((finalize_slab_kernel<1>), dim3(1), block, 0, c.stream, slab, vb[r], W[r].buf + at);
+  };
+  CgnrState *hst = static_cast<CgnrState *>(c.pinned);
+
+  // r = b - A x;  t = A^T r;  p = t;  <b,b>, <r,r>, gamma = <t,t>
+  each([&](int r) { if (nl[r]) hipLaunchKernelGGL(copy_kernel, dim3(vb[r]), dim3(256), 0, c.stream, W[r].r, b[r]->d, nl[r]); });
+  MK_D(dist_spmv(R, A, xv.data(), rv.data(), -1.0, 1.0, nullptr));
+  each([&](int r) { hipLaunchKernelGGL(cgnr_init_dots_kernel, dim3(vb[r]), block, 0, c.stream, nl[r], b[r]->d, W[r].r, W[r].slab1); });
+  MK_D(dist_spmv_transpose(R, A, rv.data(), tv.data(), 1.0, 0.0, nullptr));
+  each([&](int r) {
+    hipLaunchKernelGGL(cgnr_init_p_kernel, dim3(vb[r]), block, 0, c.stream, nl[r], W[r].t, W[r].p, W[r].slab2);
+    hipLaunchKernelGGL((finalize_slab_kernel<2>), dim3(1), block, 0, c.stream, W[r].slab1, vb[r], W[r].buf);
+    fold1(r, W[r].slab2, 2);
+  });
+  MK_D(dist_all_reduce(R, A, bufs.data(), 3));
+  each([&](int r) {
+    hipLaunchKernelGGL(cgnr_init_scalars_kernel, dim3(1), block, 0, c.stream, W[r].buf, W[r].buf + 2, 1, 1, S0->tol, W[r].state, W[r].norms);
+  });
+  MK_DH(hipMemcpyAsync(&hst[0], W[0].state, sizeof(CgnrState), hipMemcpyDeviceToHost, c.stream));
+  MK_DH(hipStreamSynchronize(c.stream));
+  const bool zero_rhs = (hst[0].bi_prod == 0.0);
+  if (zero_rhs)   // hypre: zero right-hand side -> x = b, no iterations
+    each([&](int r) { if (nl[r]) hipLaunchKernelGGL(copy_kernel, dim3(vb[r]), dim3(256), 0, c.stream, x[r]->d, b[r]->d, nl[r]); });
+
+  bool stop = zero_rhs;
+  for (int it = 0; it < S0->max_iter && !stop; it++) {
+    MK_D(dist_spmv(R, A, pv.data(), qv.data(), 1.0, 0.0, done.data()));                      // q = A p
+    each([&](int r) {
+      hipLaunchKernelGGL(dot2_kernel, dim3(vb[r]), block, 0, c.stream, nl[r], W[r].q, W[r].q, (const double *)nullptr, (const double *)nullptr, W[r].slab1,
+                         done[r], nt[r]);
+      fold1(r, W[r].slab1, 0);
+    });
+    MK_D(dist_all_reduce(R, A, bufs.data(), 1));                                             // <q,q>
+    each([&](int r) {
+      hipLaunchKernelGGL(cgnr_step1_kernel, dim3(vb[r]), block, 0, c.stream, nl[r], W[r].p, W[r].q, x[r]->d, W[r].r, W[r].buf, 1, W[r].slab2, W[r].state,
+                         nt[r]);
+    });
+    MK_D(dist_spmv_transpose(R, A, rv.data(), tv.data(), 1.0, 0.0, done.data()));            // t = A^T r
+    each([&](int r) {
+      hipLaunchKernelGGL(dot2_kernel, dim3(vb[r]), block, 0, c.stream, nl[r], W[r].t, W[r].t, (const double *)nullptr, (const double *)nullptr, W[r].slab3,
+                         done[r], nt[r]);
+      fold1(r, W[r].slab2, 0);
+      fold1(r, W[r].slab3, 1);
+    });
+    MK_D(dist_all_reduce(R, A, bufs.data(), 2));                                             // <r,r>, <t,t>
+    each([&](int r) { hipLaunchKernelGGL(cgnr_norm_kernel, dim3(1), block, 0, c.stream, W[r].buf, W[r].buf + 1, 1, W[r].state, W[r].norms); });
+    // only when <r,r> passed: r = b - A x and its norm (the fold + all-reduce run either way: the host cannot know without a
+    // wait; step 2 reads the value only behind a candidate)
+    each([&](int r) { if (nl[r]) hipLaunchKernelGGL(copy_unless_kernel, dim3(vb[r]), dim3(256), 0, c.stream, W[r].r, b[r]->d, nl[r], skip[r]); });
+    MK_D(dist_spmv(R, A, xv.data(), rv.data(), -1.0, 1.0, skip.data()));
+    each([&](int r) {
+      hipLaunchKernelGGL(dot2_kernel, dim3(vb[r]), block, 0, c.stream, nl[r], W[r].r, W[r].r, (const double *)nullptr, (const double *)nullptr, W[r].slab1,
+                         skip[r], nt[r]);
+      fold1(r, W[r].slab1, 0);
+    });
+    MK_D(dist_all_reduce(R, A, bufs.data(), 1));
+    each([&](int r) { hipLaunchKernelGGL(cgnr_step2_kernel, dim3(vb[r]), block, 0, c.stream, nl[r], W[r].t, W[r].p, W[r].buf, 1, W[r].state, nt[r]); });
+    if ((it + 1) % S0->check_every == 0) {
+      MK_DH(hipMemcpyAsync(&hst[0], W[0].state, sizeof(CgnrState), hipMemcpyDeviceToHost, c.stream));
+      MK_DH(hipStreamSynchronize(c.stream));
+      if (hst[0].done != 0) stop = true;
+    }
+  }
+  MK_DH(hipGetLastError());
+  MK_DH(hipMemcpyAsync(&hst[0], W[0].state, sizeof(CgnrState), hipMemcpyDeviceToHost, c.stream));
+  MK_DH(hipDeviceSynchronize());
+  for (int r = 0; r < R; r++) {
+    mk_cgnr *S = solvers[r];
+    S->iterations = zero_rhs ? 0 : hst[0].iter;
+    S->converged = zero_rhs ? 0 : hst[0].converged;
+    S->rel_res_norm = hst[0].bi_prod > 0.0 ? sqrt(hst[0].i_prod / hst[0].bi_prod) : 0.0;
+    if (want_norms) {
+      dev_free(S->norms);
+      S->norms = W[r].norms;
+      S->norms_cap = S0->max_iter + 1;
+      W[r].norms = nullptr;
+    }
+  }
+  cleanup();
+#undef MK_D
+#undef MK_DH
+  return MK_OK;
 }
 
 int mk_cgnr_destroy(mk_cgnr *S) {

@@ -291,6 +291,11 @@ static void release_dist(mk_dist_matrix *D) {
   freem(D->diag);
   freem(D->offd);
   dev_free(D->offd_rows); dev_free(D->ghost_global); dev_free(D->send_idx); dev_free(D->sendbuf);
+  if (D->diagT) mk_matrix_destroy(D->diagT);
+  if (D->offdT) mk_matrix_destroy(D->offdT);
+  D->diagT = D->offdT = nullptr;
+  dev_free(D->ghost_out); dev_free(D->recvbuf);
+  D->ghost_out = D->recvbuf = nullptr;
 }
 
 // split a local row block with GLOBAL column ids into diag + offd and list its ghosts
@@ -572,6 +577,79 @@ struct DistWork {
     dev_free(r); dev_free(p); dev_free(s); dev_free(slab1); dev_free(slab2); dev_free(buf); dev_free(state); dev_free(norms);
   }
 };
+
+// ------------------------------------------------------------------- transposed product
+static __global__ void map_cols_kernel(int64_t nnz, int *__restrict__ col, const int *__restrict__ map) {
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nnz; k += (int64_t)gridDim.x * blockDim.x) col[k] = map[col[k]];
+}
+
+// y[rows[i]] += alpha v[i]; the rows one neighbour contributes to are distinct, so no two threads meet
+static __global__ void scatter_add_kernel(int n, const int *__restrict__ rows, const double *__restrict__ v, double *__restrict__ y, double alpha,
+                                          const int *__restrict__ skip) {
+  if (skip != nullptr && *skip != 0) return;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) y[rows[i]] += alpha * v[i];
+}
+
+static int build_dist_transpose(mk_dist_matrix *D) {
+  Context &c = ctx();
+  if (D->diagT) return MK_OK;
+  MK_TRY(build_transpose(&D->diag, &D->diagT));
+  MK_TRY(analyse_matrix(D->diagT));
+  if (D->n_ghost > 0 && D->offd.nnz > 0) {
+    MK_TRY(build_transpose(&D->offd, &D->offdT));   // n_ghost x n_offd_rows: columns are compressed row numbers
+    hipLaunchKernelGGL(map_cols_kernel, dim3(grid1(D->offdT->nnz, 4096)), dim3(256), 0, c.stream, D->offdT->nnz, D->offdT->col, D->offd_rows);
+    D->offdT->ncols = D->n_local;                   // offd_rows ascends: the mapped columns of a row stay sorted
+    MK_TRY(analyse_matrix(D->offdT));
+    MK_TRY(dev_alloc(&D->ghost_out, (size_t)D->n_ghost));
+  }
+  if (D->n_send > 0) MK_TRY(dev_alloc(&D->recvbuf, (size_t)D->n_send));
+  MK_HIP(hipStreamSynchronize(c.stream));
+  return MK_OK;
+}
+
+int dist_spmv_transpose(int R, mk_dist_matrix **A, double **x, double **y, double alpha, double beta, const int *const *skip) {
+  Context &c = ctx();
+  for (int r = 0; r < R; r++) MK_TRY(build_dist_transpose(A[r]));
+  const bool comm = A[0]->comm != nullptr;
+  // what my rows contribute to the others' rows
+  for (int r = 0; r < R; r++)
+    if (A[r]->offdT) MK_TRY(launch_spmv(A[r]->offdT, 1.0, x[r], 0.0, A[r]->ghost_out, skip ? skip[r] : nullptr));
+  // ... goes back along the plan (send and receive sides swapped) on the communication stream, beside diag^T x
+  if (comm && A[0]->comm->local) {
+    LocalWorld *W = A[0]->comm->world;
+    MK_HIP(hipEventRecord(W->ev_ready, c.stream));
+    MK_HIP(hipStreamWaitEvent(W->side, W->ev_ready, 0));
+    for (int r = 0; r < R; r++)
+      for (int q = 0; q < R; q++)
+        if (A[r]->send_cnt[q])
+          MK_HIP(hipMemcpyAsync(A[r]->recvbuf + A[r]->send_off[q], A[q]->ghost_out + A[q]->recv_off[r], sizeof(double) * A[r]->send_cnt[q],
+                                hipMemcpyDeviceToDevice, W->side));
+    MK_HIP(hipEventRecord(W->ev_done, W->side));
+  } else if (comm) {
+    mk_dist_matrix *D = A[0];
+    mk_comm *cm = D->comm;
+    MK_HIP(hipEventRecord(cm->ev_ready, c.stream));
+    MK_HIP(hipStreamWaitEvent(cm->comm_stream, cm->ev_ready, 0));
+    MK_NCCL(g_rccl.GroupStart());
+    for (int q = 0; q < D->nranks; q++) {
+      if (D->recv_cnt[q]) MK_NCCL(g_rccl.Send(D->ghost_out + D->recv_off[q], (size_t)D->recv_cnt[q], ncclDouble, q, cm->p2p, cm->comm_stream));
+      if (D->send_cnt[q]) MK_NCCL(g_rccl.Recv(D->recvbuf + D->send_off[q], (size_t)D->send_cnt[q], ncclDouble, q, cm->p2p, cm->comm_stream));
+    }
+    MK_NCCL(g_rccl.GroupEnd());
+    MK_HIP(hipEventRecord(cm->ev_halo, cm->comm_stream));
+  }
+  for (int r = 0; r < R; r++) MK_TRY(launch_spmv(A[r]->diagT, alpha, x[r], beta, y[r], skip ? skip[r] : nullptr));
+  for (int r = 0; r < R; r++) {
+    MK_TRY(halo_wait(A[r], true));
+    mk_dist_matrix *D = A[r];
+    for (int q = 0; q < D->nranks; q++)
+      if (D->plan_ready && D->send_cnt[q])
+        hipLaunchKernelGGL(scatter_add_kernel, dim3(grid1(D->send_cnt[q], 1024)), dim3(256), 0, c.stream, D->send_cnt[q], D->send_idx + D->send_off[q],
+                           D->recvbuf + D->send_off[q], y[r], alpha, skip ? skip[r] : nullptr);
+  }
+  MK_HIP(hipGetLastError());
+  return MK_OK;
+}
 
 int dist_spmv(int R, mk_dist_matrix **A, double **x, double **y, double alpha, double beta, const int *const *skip) {
   MK_TRY(halo_exchange(R, A, x, true));

@@ -41,6 +41,11 @@ struct mk_dist_matrix {
   int *send_idx = nullptr;     // device: local rows to pack, grouped by destination
   double *sendbuf = nullptr;
   bool plan_ready = false;
+  // transposed product (CGNR), built at first use: diag^T, offd^T with the columns mapped back to local rows
+  // (n_ghost x n_local: row g = what this rank's rows contribute to ghost column g), its result, and what the
+  // neighbours contribute to the rows of the send plan
+  mk_matrix *diagT = nullptr, *offdT = nullptr;
+  double *ghost_out = nullptr, *recvbuf = nullptr;
 };
 
 
@@ -52,6 +57,11 @@ int dist_check_ranks(const char *who, int R, mk_dist_matrix **A);
 // the diag-block product, then the off-rank block; `skip` (per rank, may be null): device flags, nonzero -> that rank's kernels
 // return at once (the exchange itself always runs: it is collective)
 int dist_spmv(int R, mk_dist_matrix **A, double **x, double **y, double alpha, double beta, const int *const *skip);
+// y[r] = alpha A^T x[r] + beta y[r] on every rank (collective; x[r], y[r]: n_local entries).  The transpose of a row block
+// is a column block: diag^T x gives the owned part, offd^T x what this rank's rows contribute to the rows of OTHER ranks;
+// those go back along the exchange plan in reverse (the ghosts' owners receive and add, neighbour by neighbour in rank
+// order: fixed summation order)
+int dist_spmv_transpose(int R, mk_dist_matrix **A, double **x, double **y, double alpha, double beta, const int *const *skip);
 // sum over all ranks of bufs[r][0 .. count), in place (RCCL all-reduce, or one kernel in a local world)
 int dist_all_reduce(int R, mk_dist_matrix **A, double **bufs, int count);
 

@@ -35,6 +35,7 @@ def _lib():
         L.mk_dist_jacobi_solve.argtypes = [C.c_int, C.POINTER(P), C.POINTER(P), C.POINTER(P), C.POINTER(P)]
         L.mk_dist_bicgstab_solve.argtypes = [C.c_int, C.POINTER(P), C.POINTER(P), C.POINTER(P), C.POINTER(P)]
         L.mk_dist_gmres_solve.argtypes = [C.c_int, C.POINTER(P), C.POINTER(P), C.POINTER(P), C.POINTER(P)]
+        L.mk_dist_cgnr_solve.argtypes = [C.c_int, C.POINTER(P), C.POINTER(P), C.POINTER(P), C.POINTER(P)]
         _sigs_done = True
     return L
 
@@ -42,7 +43,7 @@ def _lib():
 DIST_EXPORTS = ["mk_comm_get_unique_id", "mk_comm_create", "mk_comm_create_local", "mk_comm_self_test", "mk_comm_all_reduce_host", "mk_comm_destroy",
                 "mk_dist_matrix_create", "mk_dist_matrix_destroy", "mk_dist_matrix_get_info", "mk_dist_matrix_set_spmv_kernel",
                 "mk_dist_vector_create", "mk_dist_spmv", "mk_dist_pcg_solve", "mk_dist_jacobi_solve",
-                "mk_dist_bicgstab_solve", "mk_dist_gmres_solve"]
+                "mk_dist_bicgstab_solve", "mk_dist_gmres_solve", "mk_dist_cgnr_solve"]
 
 
 # ------------------------------------------------------------------ host-side helpers (no GPU)
@@ -222,6 +223,19 @@ def dist_gmres_solve(solvers, As, bs, xs):
         _ck(L.mk_gmres_get_num_iterations(S.h, C.byref(it)))
         _ck(L.mk_gmres_get_final_relative_residual_norm(S.h, C.byref(nrm)))
         _ck(L.mk_gmres_get_converged(S.h, C.byref(cv)))
+        out.append(dict(iterations=it.value, rel_res_norm=nrm.value, converged=cv.value))
+    return out
+
+
+def dist_cgnr_solve(solvers, As, bs, xs):
+    L = _lib()
+    _ck(L.mk_dist_cgnr_solve(len(As), _arr(solvers), _arr(As), _arr(bs), _arr(xs)))
+    out = []
+    for S in solvers:
+        it, nrm, cv = C.c_longlong(), C.c_double(), C.c_int()
+        _ck(L.mk_cgnr_get_num_iterations(S.h, C.byref(it)))
+        _ck(L.mk_cgnr_get_final_relative_residual_norm(S.h, C.byref(nrm)))
+        _ck(L.mk_cgnr_get_converged(S.h, C.byref(cv)))
         out.append(dict(iterations=it.value, rel_res_norm=nrm.value, converged=cv.value))
     return out
 

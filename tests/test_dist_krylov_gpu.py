@@ -146,3 +146,66 @@ def test_dist_krylov_rejects_mismatched_settings_and_foreign_vectors():
         mkd.dist_gmres_solve([mk.GMRES(), mk.GMRES()], As, bs, plain)
     with pytest.raises(mk.MkError, match="all of them"):
         mkd.dist_bicgstab_solve([mk.BiCGSTAB()], As[:1], bs[:1], xs[:1])
+
+
+@pytest.mark.parametrize("world,kind,dims,cuts", [(1, 7, (14, 12, 10), None), (2, 7, (14, 12, 10), None), (3, 5, (40, 32, 1), None),
+                                                  (4, 7, (14, 12, 10), [0, 500, 500, 1100, 1680])])
+def test_dist_cgnr_matches_oracle(world, kind, dims, cuts):
+    rp, ci, v, n = _convection_diffusion(kind, dims)
+    bh = np.random.default_rng(12).normal(size=n)
+    tol = 1e-8
+    o = oracle.cgnr(rp, ci, v, bh, tol=tol, maxit=5000, want_norms=True)
+    rs = np.array(cuts, np.int64) if cuts else mkd.even_row_start(n, world)
+    As = _blocks(rp, ci, v, n, rs, _world(world))
+    for check_every in (1, 16):
+        bs = [A.vector(values=bh[rs[k]:rs[k + 1]]) for k, A in enumerate(As)]
+        xs = [A.vector(fill=0.0) for A in As]
+        Ss = [mk.CGNR(max_iter=5000, tol=tol, logging=1, check_every=check_every) for _ in As]
+        res = mkd.dist_cgnr_solve(Ss, As, bs, xs)
+        assert all(q == res[0] for q in res)
+        assert res[0]["converged"] == 1 == o["converged"]
+        assert abs(res[0]["iterations"] - o["iterations"]) <= max(2, 0.02 * o["iterations"]), (res[0], o["iterations"])
+        xg = np.concatenate([x.get() for x in xs])
+        true_rel = _true_rel(rp, ci, v, bh, xg)
+        assert true_rel < tol and abs(res[0]["rel_res_norm"] - true_rel) <= 1e-3 * tol
+        assert np.linalg.norm(xg - o["x"]) <= 1e-5 * np.linalg.norm(o["x"])
+        hist = Ss[-1].residual_history(6000)
+        assert hist.size == res[0]["iterations"] + 1
+        m = min(hist.size, o["rel_norms"].size, 30)
+        assert np.allclose(hist[:m], o["rel_norms"][:m], rtol=1e-8)
+
+
+def test_dist_cgnr_far_from_symmetric_all_to_all_and_zero_rhs():
+    """random rows (every rank's rows touch columns of every other rank, nothing symmetric): the reverse exchange must carry
+    the real transpose; a fixed number of steps against the oracle, then the zero right-hand side"""
+    rng = np.random.default_rng(13)
+    n, world = 3000, 4
+    lens = rng.integers(1, 7, n)
+    rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    ci = np.concatenate([np.sort(rng.choice(n, k, replace=False)) for k in lens]).astype(np.int32)
+    v = rng.normal(size=rp[-1])
+    rows = np.repeat(np.arange(n), lens)
+    hit = ci == rows
+    v[hit] = 8.0 + rng.uniform(0, 1, int(hit.sum()))
+    # rows without a diagonal entry get one (kept sorted)
+    need = np.setdiff1d(np.arange(n), rows[hit])
+    r2 = np.concatenate([rows, need]); c2 = np.concatenate([ci, need]).astype(np.int32); v2 = np.concatenate([v, 8.0 + rng.uniform(0, 1, need.size)])
+    order = np.lexsort((c2, r2))
+    r2, c2, v2 = r2[order], c2[order], v2[order]
+    rp2 = np.concatenate([[0], np.cumsum(np.bincount(r2, minlength=n))]).astype(np.int32)
+    rs = mk.partition_rows(rp2, world)
+    As = _blocks(rp2, c2, v2, n, rs, _world(world))
+    assert max(A.info()["n_neighbors"] for A in As) == world - 1
+    bh = rng.normal(size=n)
+    bs = [A.vector(values=bh[rs[k]:rs[k + 1]]) for k, A in enumerate(As)]
+    xs = [A.vector(fill=0.0) for A in As]
+    Ss = [mk.CGNR(max_iter=6, tol=1e-14) for _ in As]
+    res = mkd.dist_cgnr_solve(Ss, As, bs, xs)
+    o = oracle.cgnr(rp2, c2, v2, bh, tol=1e-14, maxit=6)
+    assert res[0]["iterations"] == 6 and res[0]["converged"] == 0
+    assert np.isclose(res[0]["rel_res_norm"], o["rel_res_norm"], rtol=1e-9)
+    assert np.allclose(np.concatenate([x.get() for x in xs]), o["x"], rtol=1e-9, atol=1e-13)
+    b0 = [A.vector(fill=0.0) for A in As]
+    x0 = [A.vector(fill=2.0) for A in As]
+    r0 = mkd.dist_cgnr_solve(Ss, As, b0, x0)
+    assert r0[0]["iterations"] == 0 and all(np.all(x.get() == 0.0) for x in x0)

@@ -444,6 +444,27 @@ def test_driver_row_block_path_one_rank(tmp_path, solver, precond):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("solver,label", [(6, "ParCSRBiCGSTABC"), (12, "GMRES"), (40, "CGNR")])
+def test_driver_row_block_path_one_rank_other_krylov_solvers(tmp_path, solver, label):
+    """`solver -dist -solver 6|12|40`: mk_dist_bicgstab_solve / mk_dist_gmres_solve / mk_dist_cgnr_solve behind the np > 1 code
+    path of the driver, over a real one-rank RCCL communicator"""
+    mtx = tmp_path / "poisson.mtx"
+    dims = (24, 20) if solver == 40 else (48, 40)
+    rp, ci, v = _write_poisson(mtx, *dims, shuffle_seed=7)
+    ones = np.ones(rp.size - 1)
+    o = {6: lambda: oracle.bicgstab(rp, ci, v, ones, tol=1e-8, maxit=5000),
+         12: lambda: oracle.gmres(rp, ci, v, ones, tol=1e-8, maxit=5000, k_dim=30),
+         40: lambda: oracle.cgnr(rp, ci, v, ones, tol=1e-8, maxit=5000)}[solver]()
+    out = subprocess.run([os.path.join(HOST, "solver"), "-solver", str(solver), "-mtx", str(mtx), "-tol", "1e-8", "-maxit", "5000",
+                          "-log", "0", "-dist", "-id_file", str(tmp_path / "id.bin")], capture_output=True, text=True, timeout=180, cwd=tmp_path)
+    assert out.returncode == 0, out.stderr
+    assert re.search(rf"^{label} Solve time = [0-9.]+ seconds$", out.stdout, re.M) and "Ranks = 1" in out.stdout
+    it = int(re.search(r"^Iterations = (\d+)$", out.stdout, re.M).group(1))
+    nrm = float(re.search(r"^Final Relative Residual Norm = ([0-9.e+-]+)$", out.stdout, re.M).group(1))
+    assert abs(it - o["iterations"]) <= max(3, 0.05 * o["iterations"]) and nrm <= 1e-8
+
+
+@pytest.mark.gpu
 def test_driver_rejects_stale_cache(tmp_path):
     mtx = tmp_path / "poisson.mtx"
     _write_poisson(mtx, 20, 20)
