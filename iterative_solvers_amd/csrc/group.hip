@@ -227,8 +227,11 @@ __global__ __launch_bounds__(kGThreads) void spmv_group_kernel(
     double beta, double *__restrict__ slab, const int *__restrict__ done, int cap, int ccap) {
   if (done != nullptr && *done != 0) return;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  double *sval = reinterpret_cast<double *>(smem_raw);                     // cap + 2 doubles
-  int *scol = reinterpret_cast<int *>(smem_raw + (size_t)(cap + 2) * 8);   // ccap + 8 ints
+  double *sval = reinterpret_cast<double *>(smem_raw);                     // cap + 2 doubles of stage, then a zero (below)
+  int *scol = reinterpret_cast<int *>(smem_raw + (size_t)(cap + 4) * 8);   // ccap + 8 ints
+  // Groups of EMPTY rows (and the lanes of a cut chunk that own no group) multiply nothing, but their lanes run the
+  // multiply-adds of their wave with xv = 0: they must read a finite number, not whatever lies behind the staged span.
+  if (threadIdx.x == 0) sval[cap + 2] = 0.0;   // (visible after the first barrier of the loop; never overwritten by the stage)
   constexpr int NV = 2 * U, NI = U;
   const int tid = threadIdx.x;
   const int g = tid % G, rl = tid / G;
@@ -300,7 +303,7 @@ __global__ __launch_bounds__(kGThreads) void spmv_group_kernel(
     const gi4_t nnce2 = cdesc[2 * next2 + 1];
     const gi4_t ngd = gdesc[min(nce2.x + rl, ngroups)];
     __syncthreads();
-    const double *sv = sval + (cb - vb) + b0;   // sv[m * len + j]: value of list entry j in the group's m-th row
+    const double *sv = (len > 0) ? sval + (cb - vb) + b0 : sval + cap + 2;   // sv[m * len + j]: value of list entry j in the group's m-th row
     const int *sc = scol + cs;
     // The lane's first 8 list entries: all gathers issued before anything waits.  Slots no lane of the wave needs are skipped
     // by wave-uniform branches (an exec-masked slot would still take its issue cycles: with 78-entry lists on 16 lanes five
@@ -407,7 +410,7 @@ template <int MODE, int U, bool NT>
 static int launch_group_u(const mk_matrix *A, double alpha, const double *x, double beta, double *y, double *slab, const int *done, int *nblocks) {
   Context &c = ctx();
   const int G = A->group_lanes, cap = A->group_cap, ccap = A->group_ccap;
-  const size_t lds = (size_t)(cap + 2) * 8 + (size_t)(ccap + 8) * 4;
+  const size_t lds = (size_t)(cap + 4) * 8 + (size_t)(ccap + 8) * 4;
   const int nchunks = A->group_chunks;
   static const int env_bpc = getenv("MK_GROUP_BPC") ? atoi(getenv("MK_GROUP_BPC")) : 0;
   int per_cu = env_bpc > 0 ? env_bpc : A->group_bpc[MODE];
