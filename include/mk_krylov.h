@@ -201,6 +201,16 @@ int mk_pcg_set_print_level(mk_pcg *solver, int level);            /* HYPRE_PCGSe
 int mk_pcg_set_logging(mk_pcg *solver, int logging);              /* HYPRE_PCGSetLogging :744 */
 int mk_pcg_set_precond(mk_pcg *solver, int precond);              /* extension id 51: HYPRE_ParCSRDiagScale semantics */
 int mk_pcg_set_check_every(mk_pcg *solver, int iterations);       /* how often the host reads the device-side stop flag */
+/* Row-block solves only (mk_dist_pcg_solve), opt-in, default off.  The loop of hypre_PCGSolve that solvers.c:753-754 runs
+ * under mpirun reduces twice per iteration (<A p, p> in front of alpha, <r,z> in front of beta: two MPI_Allreduce inside
+ * HYPRE).  With on = 1 the step needs ONE all-reduce of five doubles: <A p', p'> for p' = z + beta p comes from <A z, z>
+ * by the Chronopoulos-Gear identity, <A z, z> - beta gamma' / alpha_old, so it is known before p' is formed.  Same
+ * iterates in exact arithmetic, same stopping rule; in floating point alpha differs in its last bits (tests: iteration
+ * counts within 2, residual history to 1e-8 against the two-reduction loop).  Taken only when every rank's diagonal block
+ * runs on the sweep kernel with no or a uniform-diagonal Jacobi preconditioner (the ranks agree on that at the start of the
+ * solve); otherwise the default step runs.  mk_pcg_get_single_reduction reports what the last row-block solve took. */
+int mk_pcg_set_single_reduction(mk_pcg *solver, int on);
+int mk_pcg_get_single_reduction(const mk_pcg *solver, int *used);
 /* measurement hook (bench.py's roofline figures; SURVEY.md 8(d) "hipEvent around the iterations"): with on = 1 the next
  * mk_pcg_solve records a HIP event in front of every kernel of its iterations 2..33 on the library's stream;
  * get returns, per kernel slot of a step (0: SpMV + dots, 1: x/r update, 2: direction update when it is a kernel of

@@ -56,7 +56,7 @@ EXPORTS = [
     "mk_vector_size", "mk_spmv", "mk_spmv_dot", "mk_spmv_dot_static",
     "mk_pcg_create", "mk_pcg_set_max_iter", "mk_pcg_set_tol", "mk_pcg_set_two_norm",
     "mk_pcg_set_rel_change", "mk_pcg_set_print_level", "mk_pcg_set_logging", "mk_pcg_set_precond",
-    "mk_pcg_set_check_every", "mk_pcg_set_kernel_timing", "mk_pcg_get_kernel_timing", "mk_pcg_setup", "mk_pcg_solve", "mk_pcg_get_num_iterations",
+    "mk_pcg_set_check_every", "mk_pcg_set_single_reduction", "mk_pcg_get_single_reduction", "mk_pcg_set_kernel_timing", "mk_pcg_get_kernel_timing", "mk_pcg_setup", "mk_pcg_solve", "mk_pcg_get_num_iterations",
     "mk_pcg_get_final_relative_residual_norm", "mk_pcg_get_converged",
     "mk_pcg_get_residual_history", "mk_pcg_destroy",
     "mk_bicgstab_create", "mk_bicgstab_set_max_iter", "mk_bicgstab_set_tol", "mk_bicgstab_set_print_level",
@@ -125,6 +125,7 @@ def load():
         "mk_pcg_set_print_level": [P, C.c_int], "mk_pcg_set_logging": [P, C.c_int],
         "mk_pcg_set_precond": [P, C.c_int], "mk_pcg_set_check_every": [P, C.c_int],
         "mk_pcg_set_kernel_timing": [P, C.c_int],
+        "mk_pcg_set_single_reduction": [P, C.c_int], "mk_pcg_get_single_reduction": [P, C.POINTER(C.c_int)],
         "mk_pcg_get_kernel_timing": [P, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.c_int],
         "mk_pcg_setup": [P, P, P, P], "mk_pcg_solve": [P, P, P, P],
         "mk_pcg_get_num_iterations": [P, C.POINTER(C.c_longlong)],
@@ -457,6 +458,15 @@ class PCG:
 
     def set_kernel_timing(self, on=True):
         _ck(load().mk_pcg_set_kernel_timing(self.h, int(on)))
+
+    def set_single_reduction(self, on=True):
+        """row-block solves: one all-reduce per iteration (Chronopoulos-Gear form of alpha); opt-in"""
+        _ck(load().mk_pcg_set_single_reduction(self.h, int(on)))
+
+    def single_reduction_used(self):
+        u = C.c_int()
+        _ck(load().mk_pcg_get_single_reduction(self.h, C.byref(u)))
+        return bool(u.value)
 
     def kernel_timing(self):
         """[(average ms, launches)] per kernel slot of a CG step, measured by HIP events inside the last solve"""

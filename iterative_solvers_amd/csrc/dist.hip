@@ -567,13 +567,53 @@ static __global__ void offd_resid_kernel(int nrows, const int *__restrict__ rows
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nrows; i += gridDim.x * blockDim.x) r[rows[i]] -= alpha * t[i];
 }
 
+// ---- single-reduction step (opt-in, mk_pcg_set_single_reduction): small kernels around spmv_sweep_kernel MODE 6
+// out[0] = sum of component 0 of slab_a (<A r, r>: diag sweep + off-rank product); out[1..4] = the four components the last
+// MODE 6 sweep left in slab_b (<r,z>, <r,r>, <x,x>, <p,p>; nb = 0 before the first step: zeros)
+static __global__ __launch_bounds__(kVecThreads) void single_fold_kernel(const double *slab_a, int na, const double *slab_b, int nb, double *out) {
+  __shared__ double smem[4 * (kVecThreads / 64)];
+  double a[1], b[4];
+  reduce_slab<1, kVecThreads>(slab_a, na, kSlabStride, a, smem);
+  reduce_slab<4, kVecThreads>(slab_b, nb, kSlabStride, b, smem);
+  if (threadIdx.x == 0) {
+    out[0] = a[0];
+    for (int k = 0; k < 4; k++) out[1 + k] = b[k];
+  }
+}
+// tpf[rows[i]] = zscale t[i] + beta tpf[rows[i]]: the off-rank part of A p' follows p' = z + beta p (t = off-rank part of
+// A r; beta as MODE 6's prologue forms it from the same all-reduced values)
+static __global__ void single_offd_kernel(int nrows, const int *__restrict__ rows, const double *__restrict__ t, double *__restrict__ tpf,
+                                          const double *__restrict__ buf, const PcgState *st, double zscale, int first, int parity) {
+  if (st->done != 0) return;
+  const double beta = first ? 0.0 : buf[1] / st->sr_gamma[parity ^ 1];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nrows; i += gridDim.x * blockDim.x) {
+    const int r = rows[i];
+    tpf[r] = zscale * t[i] + beta * tpf[r];
+  }
+}
+// the convergence test the next step's prologue would have made (after the last step of a solve)
+static __global__ void single_final_test_kernel(const double *__restrict__ buf, PcgState *st, int flags, double *__restrict__ norms, int parity) {
+  if (threadIdx.x != 0 || blockIdx.x != 0 || st->done != 0) return;
+  const double gamma_new = buf[1], i_prod = (flags & 1) ? buf[2] : buf[1], al = st->sr_alpha[parity ^ 1];
+  bool conv = (i_prod / st->bi_prod < st->eps);
+  if (conv && (flags & 2) && i_prod > 0.0) {
+    const double ratio = al * al * buf[4] / buf[3];
+    if (ratio >= st->eps) conv = false;
+  }
+  st->gamma = gamma_new;
+  st->i_prod = i_prod;
+  if (norms) norms[st->iter] = sqrt(i_prod / st->bi_prod);
+  if (conv) { st->converged = 1; st->done = 1; }
+}
+
 struct DistWork {
   double *r = nullptr, *p = nullptr, *s = nullptr, *slab1 = nullptr, *slab2 = nullptr, *buf = nullptr, *norms = nullptr;
   double *t = nullptr;   // fused step: off-rank part of A p over the rows that touch ghosts
   double *p2 = nullptr;  // fused step: the other p buffer (K3 folded into the first sweep writes p' there)
+  double *tpf = nullptr; // single-reduction step: off-rank part of A p over the local rows (zero where a row touches no ghost)
   PcgState *state = nullptr;
   void release() {
-    dev_free(t); dev_free(p2);
+    dev_free(t); dev_free(p2); dev_free(tpf);
     dev_free(r); dev_free(p); dev_free(s); dev_free(slab1); dev_free(slab2); dev_free(buf); dev_free(state); dev_free(norms);
   }
 };
@@ -965,6 +1005,8 @@ int mk_dist_pcg_solve(int R, mk_pcg **solvers, mk_dist_matrix **A, mk_vector **b
   static const int no_fused = getenv("MK_NO_FUSED_CG") ? atoi(getenv("MK_NO_FUSED_CG")) : 0;
   static const int no_pfuse = getenv("MK_NO_FUSED_K3") ? atoi(getenv("MK_NO_FUSED_K3")) : 0;
   static const int no_beside = getenv("MK_NO_OFFD_OVERLAP") ? atoi(getenv("MK_NO_OFFD_OVERLAP")) : 0;   // A/B: off-rank product after the sweep
+  static const int env_single = getenv("MK_CG_SINGLE_REDUCE") ? atoi(getenv("MK_CG_SINGLE_REDUCE")) : -1;   // tests / A/B: force the variant on or off
+  const bool want_single = env_single >= 0 ? env_single != 0 : S0->single_reduction != 0;
   int rc = MK_OK;
   auto cleanup = [&]() { (void)hipDeviceSynchronize(); for (auto &w : W) w.release(); };
 #define MK_D(expr) do { rc = (expr); if (rc != MK_OK) { cleanup(); return rc; } } while (0)
@@ -972,9 +1014,9 @@ int mk_dist_pcg_solve(int R, mk_pcg **solvers, mk_dist_matrix **A, mk_vector **b
   for (int r = 0; r < R; r++) {
     mk_dist_matrix *D = A[r];
     const size_t nl = (size_t)D->n_local, ne = (size_t)(D->n_local + D->n_ghost);
-    MK_D(dev_alloc(&W[r].r, nl));
+    MK_D(dev_alloc(&W[r].r, want_single ? ne : nl));   // (single-reduction step: r is the vector that is exchanged)
     MK_D(dev_alloc(&W[r].p, ne));
-    MK_D(dev_alloc(&W[r].s, nl));
+    MK_D(dev_alloc(&W[r].s, want_single ? ne : nl));
     MK_D(dev_alloc(&W[r].slab1, (size_t)kMaxParts * kSlabStride));
     MK_D(dev_alloc(&W[r].slab2, (size_t)kMaxParts * kSlabStride));
     MK_D(dev_alloc(&W[r].buf, 8));
@@ -994,6 +1036,27 @@ int mk_dist_pcg_solve(int R, mk_pcg **solvers, mk_dist_matrix **A, mk_vector **b
     if (pfuse[r]) MK_D(dev_alloc(&W[r].p2, ne));
     solvers[r]->iterations = 0; solvers[r]->rel_res_norm = 0.0; solvers[r]->converged = 0; solvers[r]->breakdown = 0;
   }
+  // The single-reduction step needs the sweep kernel with K3 in its window fill on EVERY rank (its one reduction carries
+  // other values than the default step's two, so ranks cannot mix): agree on it, else everybody takes the default step.
+  bool single = false;
+  if (want_single) {
+    double bad = 0.0;
+    for (int r = 0; r < R; r++) if (!pfuse[r]) bad += 1.0;
+    if (A[0]->comm != nullptr && !A[0]->comm->local) {
+      MK_DH(hipMemcpyAsync(W[0].buf, &bad, sizeof(double), hipMemcpyHostToDevice, c.stream));
+      MK_D(dist_all_reduce(R, A, bufs.data(), 1));
+      MK_DH(hipMemcpyAsync(&bad, W[0].buf, sizeof(double), hipMemcpyDeviceToHost, c.stream));
+      MK_DH(hipStreamSynchronize(c.stream));
+    }
+    single = (bad == 0.0);
+    if (single)
+      for (int r = 0; r < R; r++)
+        if (A[r]->n_offd_rows > 0) {
+          MK_D(dev_alloc(&W[r].tpf, (size_t)A[r]->n_local));
+          MK_DH(hipMemsetAsync(W[r].tpf, 0, sizeof(double) * (size_t)A[r]->n_local, c.stream));
+        }
+  }
+  for (int r = 0; r < R; r++) solvers[r]->single_reduction_used = single ? 1 : 0;
   PcgState *hst = static_cast<PcgState *>(c.pinned);
   const int two_norm = S0->two_norm, rel_change = S0->rel_change;
 
@@ -1027,6 +1090,53 @@ int mk_dist_pcg_solve(int R, mk_pcg **solvers, mk_dist_matrix **A, mk_vector **b
   }
 
   bool stop = zero_rhs;
+  // ---- single-reduction step: per iteration ONE exchange (of r, no scalar in front of it), ONE all-reduce of five values, two
+  // sweeps.  K_A: <A r, r> (diag sweep, dots only) beside pack + exchange + off-rank product on the communication stream;
+  // fold + all-reduce; K_B (MODE 6): test of the step before, beta, alpha by the Chronopoulos-Gear identity, p' = z + beta p in
+  // the window fill, r' = r - alpha A p', x += alpha p', partials for the next reduction.  r and p ping-pong (W.s and W.p2
+  // are the second buffers).  60 B per row and iteration against the default step's 68.
+  if (single) {
+    std::vector<double *> rcur(R), rnew(R), pnew(R);
+    std::vector<int> nbk2(R, 0);
+    const int tflags = (two_norm ? 1 : 0) | (rel_change ? 2 : 0);
+    for (int r = 0; r < R; r++) { rcur[r] = W[r].r; rnew[r] = W[r].s; pv[r] = W[r].p; pnew[r] = W[r].p2; }
+    int it = 0;
+    for (; it < S0->max_iter && !stop; it++) {
+      const int first = (it == 0), par = it & 1;
+      MK_D(halo_exchange(R, A, rcur.data(), true));
+      for (int r = 0; r < R; r++) MK_D(launch_sweep_cg_dots(&A[r]->diag, rcur[r], W[r].slab1, W[r].state, &nb1[r]));
+      for (int r = 0; r < R; r++)
+        MK_D(launch_offd_compact(A[r], rcur[r], W[r].t, W[r].slab1 + nb1[r], &W[r].state->done, &nb2[r], kSlabStride - nb1[r], halo_stream(A[r]), nullptr));
+      MK_D(halo_mark(A[0]));
+      for (int r = 0; r < R; r++) {
+        MK_D(halo_wait(A[r], true));
+        hipLaunchKernelGGL(single_fold_kernel, dim3(1), dim3(kVecThreads), 0, c.stream, W[r].slab1, nb1[r] + nb2[r], W[r].slab2, nbk2[r], W[r].buf);
+      }
+      MK_D(dist_all_reduce(R, A, bufs.data(), 5));
+      for (int r = 0; r < R; r++) {
+        if (W[r].tpf)
+          hipLaunchKernelGGL(single_offd_kernel, dim3(grid1(A[r]->n_offd_rows, 1024)), dim3(256), 0, c.stream, A[r]->n_offd_rows, A[r]->offd_rows,
+                             W[r].t, W[r].tpf, W[r].buf, W[r].state, zs[r], first, par);
+        MK_D(launch_sweep_cg_single(&A[r]->diag, rcur[r], rnew[r], pv[r], pnew[r], x[r]->d, zs[r], W[r].tpf, W[r].tpf ? A[r]->gap0 : 0,
+                                    W[r].tpf ? A[r]->gap1 : 0, W[r].buf, W[r].slab2, W[r].state, two_norm, rel_change, first, par, W[r].norms, &nbk2[r]));
+        std::swap(rcur[r], rnew[r]);
+        std::swap(pv[r], pnew[r]);
+      }
+      if ((it + 1) % S0->check_every == 0) {
+        MK_DH(hipMemcpyAsync(&hst[0], W[0].state, sizeof(PcgState), hipMemcpyDeviceToHost, c.stream));
+        MK_DH(hipStreamSynchronize(c.stream));
+        if (hst[0].done != 0) stop = true;
+      }
+    }
+    if (it > 0 && !zero_rhs) {   // the test of the last step (one more reduction, once per solve)
+      for (int r = 0; r < R; r++)
+        hipLaunchKernelGGL(single_fold_kernel, dim3(1), dim3(kVecThreads), 0, c.stream, W[r].slab1, 0, W[r].slab2, nbk2[r], W[r].buf);
+      MK_D(dist_all_reduce(R, A, bufs.data(), 5));
+      for (int r = 0; r < R; r++)
+        hipLaunchKernelGGL(single_final_test_kernel, dim3(1), dim3(64), 0, c.stream, W[r].buf, W[r].state, tflags, W[r].norms, it & 1);
+    }
+    stop = true;   // (the default loop below does not run)
+  }
   for (int it = 0; it < S0->max_iter && !stop; it++) {
     // ranks with K3 folded into the first sweep: from the second iteration on p' = z + beta p is formed inside that
     // sweep, into the other p buffer; its send rows are formed ahead by the pack kernel so the halo can start now
@@ -1102,7 +1212,7 @@ int mk_dist_pcg_solve(int R, mk_pcg **solvers, mk_dist_matrix **A, mk_vector **b
     }
   }
   for (int r = 0; r < R; r++)   // the test the next iteration's first sweep would have made (K3's prologue; n = 0: no p update)
-    if (pfuse[r] && S0->max_iter > 0 && !zero_rhs)
+    if (pfuse[r] && S0->max_iter > 0 && !zero_rhs && !single)
       hipLaunchKernelGGL((pcg_update_p_kernel<false>), dim3(1), dim3(kVecThreads), 0, c.stream, (int64_t)0, W[r].r, (const double *)nullptr, pv[r], W[r].buf + 4, 1, 1, two_norm, rel_change, W[r].state, W[r].norms, 0);
   MK_DH(hipGetLastError());
   MK_DH(hipMemcpyAsync(&hst[0], W[0].state, sizeof(PcgState), hipMemcpyDeviceToHost, c.stream));

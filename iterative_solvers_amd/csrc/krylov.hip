@@ -64,7 +64,14 @@ MK_PCG_SETTER(mk_pcg_set_logging, logging, int, v >= 0)
 MK_PCG_SETTER(mk_pcg_set_precond, precond, int, v == MK_PRECOND_NONE || v == MK_PRECOND_JACOBI)
 MK_PCG_SETTER(mk_pcg_set_check_every, check_every, int, v >= 1)
 MK_PCG_SETTER(mk_pcg_set_kernel_timing, timing, int, v == 0 || v == 1)
+MK_PCG_SETTER(mk_pcg_set_single_reduction, single_reduction, int, v == 0 || v == 1)
 #undef MK_PCG_SETTER
+
+int mk_pcg_get_single_reduction(const mk_pcg *solver, int *used) {
+  if (!solver || !used) return fail(MK_ERR_INVALID, "mk_pcg_get_single_reduction: null argument");
+  *used = solver->single_reduction_used;
+  return MK_OK;
+}
 
 int mk_pcg_setup(mk_pcg *S, const mk_matrix *A, const mk_vector *b, const mk_vector *x) {
   MK_REQUIRE_INIT();

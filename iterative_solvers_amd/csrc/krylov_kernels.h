@@ -340,6 +340,8 @@ struct mk_pcg {
   int logging = 0;
   int precond = MK_PRECOND_NONE;
   int check_every = 16;
+  int single_reduction = 0;        // row-block solve: ask for the single-reduction step (mk_pcg_set_single_reduction)
+  int single_reduction_used = 0;   // ... and whether the last row-block solve took it
   // work space (setup)
   int64_t n = 0;
   double *r = nullptr, *p = nullptr, *s = nullptr, *p2 = nullptr;

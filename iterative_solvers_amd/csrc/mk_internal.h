@@ -91,6 +91,7 @@ struct SweepArgs {
   int kb;         // first plane of the launch (0 unless a caller sweeps a sub-range of the planes)
   int diag;       // index of the last entry with offset 0, or -1
   double dv;      // its value
+  int gap0, gap1; // MODE 6: local rows [gap0, gap1) have a zero `extra` (set per launch)
 };
 struct SweepEntry {   // one entry of the base pattern.  Device table: 4 copies x 32 entries (padded with zeros);
   int off;            // copy c serves the steps whose plane sits in ring slot c: off = byte offset in the LDS ring
@@ -109,6 +110,7 @@ struct PcgState {
   int x_pending;   // deferred solution update (vsweep CG): x += alpha p of the last completed step has not been applied yet
   int pbuf;        // ... and which of the two p buffers that p is in
   int pad;
+  double sr_alpha[2], sr_gamma[2];   // single-reduction step: alpha and gamma of the last two steps by parity (read [parity ^ 1], write [parity])
 };
 
 // grid-level reduction slabs: component k of block b lives at slab[k * stride + b]
@@ -177,7 +179,7 @@ struct mk_matrix {
   int *rowpair = nullptr;          // vsweep kernel: rowptr[0], rowptr[2], ... (first value of every lane's row pair)
   bool sweep_streamed = false;     // the plan matches column offsets only: values are streamed from val[] (spmv_vsweep_kernel)
   unsigned short *sweep_perm = nullptr;   // sweep kernel, rows of more than 8 entries: row pair each lane of a chunk owns (ncp x C/2)
-  mutable int sweep_bpc[6] = {0, 0, 0, 0, 0, 0};
+  mutable int sweep_bpc[7] = {0, 0, 0, 0, 0, 0, 0};
   bool sweep_diag_uniform = false; // every row has the (single) diagonal entry of the base pattern
   int npat = 0, pml = 0;
   int max_off = 0;                 // largest |column - row| over all patterns
@@ -233,6 +235,11 @@ int launch_sweep_cg_pdots(const mk_matrix *A, const double *r, const double *p_o
                           const double *slab_in, int nblocks_in, int stride_in, double *slab_out, PcgState *st, int two_norm,
                           int rel_change, double *norms, int *nblocks);
 int sweep_uniform_diag(const mk_matrix *A, double *inv_diag);
+//   single : the single-reduction step (opt-in): both halves of the step in one sweep behind ONE reduction of five values
+//            (<A r, r>, <r,z>, <r,r>, <x,x>, <p,p>); see spmv_sweep_kernel MODE 6.  r and p are ping-ponged by the caller.
+int launch_sweep_cg_single(const mk_matrix *A, const double *r_old, double *r_new, const double *p_old, double *p_new, double *x,
+                           double zscale, const double *extra, int gap0, int gap1, const double *sr_in, double *slab_out,
+                           PcgState *st, int two_norm, int rel_change, int first, int parity, double *norms, int *nblocks);
 int launch_sweep_cg_resid_x(const mk_matrix *A, const double *p, double *r, double *x, const double *dinv, const double *slab_in,
                             int nblocks_in, int stride_in, double *slab_out, PcgState *st, int *nblocks);
 

@@ -1328,7 +1328,7 @@ __global__ __launch_bounds__(T, T == 512 ? 2 : 1) void spmv_sweep_kernel(
     const unsigned *__restrict__ pmask, int npat, const double *__restrict__ x, double *__restrict__ y, double alpha, double beta, double *__restrict__ slab,
     const int *__restrict__ done, const double *__restrict__ rhs, const double *__restrict__ extra,
     PcgState *st, const double *__restrict__ slab_in, int nblocks_in, int stride_in, double *__restrict__ xupd,
-    int flags, double *__restrict__ norms, const unsigned short *__restrict__ perm) {
+    int flags, double *__restrict__ norms, const unsigned short *__restrict__ perm, double *__restrict__ y2) {
   // MODE 0: y = alpha A x + beta y.  1: y = A x, partials of <y,x>, <x,x>.  2: Jacobi sweep.
   // MODE 3 (fused CG, first kernel of a step): partials of <A x, x>, <x,x> only, nothing stored.
   // MODE 4 (second kernel; x is CG's p): alpha = gamma / <A x, x> from slab_in (K2's prologue), then
@@ -1338,6 +1338,15 @@ __global__ __launch_bounds__(T, T == 512 ? 2 : 1) void spmv_sweep_kernel(
   //         convergence test, beta from slab_in); the window is filled with p' = z + beta x (z = alpha * rhs, alpha = 1
   //         or the uniform 1/diag) instead of x, the block's own rows of p' go to y, then as MODE 3 on p'.
   //         flags: bit 0 two_norm, bit 1 rel_change.
+  // MODE 6 (single-reduction CG step, opt-in): MODE 5's window fill and MODE 4's body in ONE kernel behind ONE reduction.
+  //         slab_in: <A r, r>, <r,z>, <r,r>, <x,x>, <p,p> (all-reduced).  Prologue: the convergence test of the step before
+  //         (K3's), beta = gamma' / gamma, then alpha = gamma' / (zscale^2 <A r, r> - beta gamma' / alpha_old) -- the
+  //         Chronopoulos-Gear identity for <A p', p'> with p' = z + beta p, so the product A p' needs no reduction of its
+  //         own.  Window = p' (x: old p, rhs: r, alpha: zscale), own rows of p' -> y; then rhs_new = r - alpha (A p' +
+  //         extra) -> y2 (r is read through the window of OTHER blocks, so it cannot be updated in place), xupd += alpha
+  //         p', partials of <r,z>, <r,r>, <xupd,xupd>, <p',p'>.  flags: bit 2 first step (no test, beta = 0), bit 3 parity
+  //         of the step (alpha and gamma of the last step are read from st->sr_*[parity ^ 1], the new ones written to
+  //         [parity]: other blocks of this launch still read the old ones).
   if (done != nullptr && *done != 0) return;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   constexpr int C = 2 * T, NS = kSweepNS;
@@ -1345,6 +1354,7 @@ __global__ __launch_bounds__(T, T == 512 ? 2 : 1) void spmv_sweep_kernel(
   double *ring = reinterpret_cast<double *>(smem_raw);            // NS slabs of sw entries
   unsigned *smask = reinterpret_cast<unsigned *>(ring + NS * sw);   // npat
   const int tid = threadIdx.x;
+  double acg = 0.0;   // MODE 6: the step's alpha (`alpha` keeps zscale for the window fill)
   if (MODE >= 3) {
     if (block_flag_raised(&st->done)) return;
     if (MODE == 4) {   // K2's prologue
@@ -1389,12 +1399,57 @@ __global__ __launch_bounds__(T, T == 512 ? 2 : 1) void spmv_sweep_kernel(
       if (conv || tiny_gamma) return;
       beta = gamma_new / gamma_old;
     }
+    if (MODE == 6) {
+      const bool leader = (blockIdx.x == 0 && tid == 0);
+      double d[5];
+      reduce_slab<5, T>(slab_in, nblocks_in, stride_in, d, ring);
+      const int par = (flags >> 3) & 1;
+      const bool first = (flags & 4) != 0;
+      const double bi_prod = st->bi_prod, eps = st->eps, al_old = st->sr_alpha[par ^ 1], gamma_old = st->sr_gamma[par ^ 1];
+      const double gamma_new = first ? st->gamma : d[1];
+      __syncthreads();
+      if (!first) {
+        const double i_prod = (flags & 1) ? d[2] : d[1];
+        bool conv = (i_prod / bi_prod < eps);
+        if (conv && (flags & 2) && i_prod > 0.0) {
+          const double ratio = al_old * al_old * d[4] / d[3];
+          if (ratio >= eps) conv = false;
+        }
+        const bool tiny_gamma = (gamma_new < DBL_MIN) && (-gamma_new < DBL_MIN);
+        if (leader) {
+          st->gamma = gamma_new;
+          st->i_prod = i_prod;
+          if (norms) norms[st->iter] = sqrt(i_prod / bi_prod);
+          if (conv) { st->converged = 1; st->done = 1; }
+          else if (tiny_gamma) { st->breakdown = 3; st->done = 2; }
+        }
+        if (conv || tiny_gamma) return;
+        beta = gamma_new / gamma_old;
+      } else {
+        beta = 0.0;
+      }
+      const double azz = (alpha * alpha) * d[0];                                   // <A z, z>, z = zscale r
+      const double sdotp = first ? azz : azz - beta * gamma_new / al_old;          // = <A p', p'>
+      if (sdotp == 0.0) {
+        if (leader) { st->iter += 1; st->breakdown = 1; st->done = 2; }
+        return;
+      }
+      acg = gamma_new / sdotp;
+      if (!(acg > DBL_MIN)) {
+        if (leader) { st->iter += 1; st->breakdown = 2; st->done = 2; }
+        return;
+      }
+      if (leader) {
+        st->alpha = acg; st->gamma_old = gamma_new; st->sdotp = sdotp; st->iter += 1;
+        st->sr_alpha[par] = acg; st->sr_gamma[par] = gamma_new;
+      }
+    }
     __syncthreads();   // ring was reduction scratch
   }
   for (int i = tid; i < npat; i += T) smask[i] = pmask[i];
   const int nb = gridDim.x;   // multiple of 8; blocks of one XCD take neighbouring chunks of a plane (shared halos in its L2)
   const int lid = (blockIdx.x & 7) * (nb >> 3) + (blockIdx.x >> 3);
-  double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
+  double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
   if (lid < S.ncp * S.nseg) {
     // all row / column indices fit 29 bits here (plan_sweep): 32-bit arithmetic throughout, one v_med3 per clamp
     const int nr = (int)nrows;
@@ -1415,14 +1470,15 @@ __global__ __launch_bounds__(T, T == 512 ? 2 : 1) void spmv_sweep_kernel(
     // row refers to (their mask bit is clear) or are never read.
     const int xlast = ((int)ncols - 1) & ~1;   // x[xlast], x[xlast+1]: inside the allocation (slack behind ncols)
     const int rlast = (nr - 1) & ~1;
-    constexpr int NLR = (MODE == 5) ? NL : 1;   // second window stream (the residual) only in MODE 5
+    constexpr bool kFill = (MODE == 5 || MODE == 6);   // the window is p' = z + beta p, formed while it is filled
+    constexpr int NLR = kFill ? NL : 1;   // second window stream (the residual) only then
     auto load_slab = [&](int j, d2_t(&reg)[NL], d2_t(&regr)[NLR]) {   // window of plane j
       const int g0 = min(j, k1) * S.P + r0 - S.wlo + lw;
 #pragma unroll
       for (int i = 0; i < NL; i++) {
         const int g = min(max(g0 + i * 2 * T, 0), xlast);
         reg[i] = MK_SWEEP_LDW(reinterpret_cast<const d2_t *>(reinterpret_cast<const char *>(x) + ((unsigned)g << 3)));
-        if (MODE == 5) regr[i] = MK_SWEEP_LDW(reinterpret_cast<const d2_t *>(reinterpret_cast<const char *>(rhs) + ((unsigned)g << 3)));
+        if (kFill) regr[i] = MK_SWEEP_LDW(reinterpret_cast<const d2_t *>(reinterpret_cast<const char *>(rhs) + ((unsigned)g << 3)));
       }
     };
     // A slab is stored de-interleaved: window entry e at [e / 2] of the first half (e even) or of the second half (e odd).
@@ -1437,7 +1493,7 @@ __global__ __launch_bounds__(T, T == 512 ? 2 : 1) void spmv_sweep_kernel(
         const int wi = lw + i * 2 * T;   // position in the window
         if (wi < sw) {
           d2_t v = reg[i];
-          if (MODE == 5) {
+          if (kFill) {
             d2_t z = regr[i];
             z.x *= alpha;
             z.y *= alpha;
@@ -1465,15 +1521,17 @@ __global__ __launch_bounds__(T, T == 512 ? 2 : 1) void spmv_sweep_kernel(
       const int g = min(row_of(j), rlast);
       return MK_SWEEP_LD(reinterpret_cast<const d2_t *>(reinterpret_cast<const char *>(p) + ((unsigned)g << 3)));
     };
-    const double *aux = (MODE == 2 || MODE == 4) ? rhs : (MODE == 0 && beta != 0.0) ? y : nullptr;
-    constexpr bool kExtra = (MODE == 2 || MODE == 4);
+    const double *aux = (MODE == 2 || MODE == 4 || MODE == 6) ? rhs : (MODE == 0 && beta != 0.0) ? y : nullptr;
+    constexpr bool kExtra = (MODE == 2 || MODE == 4 || MODE == 6);
+    constexpr bool kXupd = (MODE == 4 || MODE == 6);
     // MODE 2, row-block Jacobi: `extra` (the off-rank product) is zero on every row that touches no ghost.  The caller names
     // the largest run of such rows [gap0, gap1) (in nblocks_in / stride_in, which this mode has no other use for): lanes
     // inside it all read the pair at gap0 -- the load stays unconditional, HBM sees one line instead of 8 B per row.
-    const int gap0 = (MODE == 2) ? nblocks_in : 0, gap1 = (MODE == 2) ? stride_in : 0;
+    // (MODE 6: the same for the off-rank part of A p', run named in S.gap0 / S.gap1)
+    const int gap0 = (MODE == 2) ? nblocks_in : (MODE == 6) ? S.gap0 : 0, gap1 = (MODE == 2) ? stride_in : (MODE == 6) ? S.gap1 : 0;
     auto load_extra = [&](int j) -> d2_t {
       int g = min(row_of(j), rlast);
-      if (MODE == 2) g = (g >= gap0 && g + 1 < gap1) ? gap0 : g;
+      if (MODE == 2 || MODE == 6) g = (g >= gap0 && g + 1 < gap1) ? gap0 : g;
       return MK_SWEEP_LD(reinterpret_cast<const d2_t *>(reinterpret_cast<const char *>(extra) + ((unsigned)g << 3)));
     };
 
@@ -1494,17 +1552,17 @@ __global__ __launch_bounds__(T, T == 512 ? 2 : 1) void spmv_sweep_kernel(
     unsigned id0 = load_ids(k0);
     if (aux) ax0 = load_pair(aux, k0);
     if (kExtra && extra) ex0 = load_extra(k0);
-    if (MODE == 4) xu0 = load_pair(xupd, k0);
+    if (kXupd) xu0 = load_pair(xupd, k0);
     load_slab(k0 + 2, st0, rt0);
     unsigned id1 = load_ids(k0 + 1);
     if (aux) ax1 = load_pair(aux, k0 + 1);
     if (kExtra && extra) ex1 = load_extra(k0 + 1);
-    if (MODE == 4) xu1 = load_pair(xupd, k0 + 1);
+    if (kXupd) xu1 = load_pair(xupd, k0 + 1);
     load_slab(k0 + 3, st1, rt1);
     unsigned id2 = load_ids(k0 + 2);
     if (aux) ax2 = load_pair(aux, k0 + 2);
     if (kExtra && extra) ex2 = load_extra(k0 + 2);
-    if (MODE == 4) xu2 = load_pair(xupd, k0 + 2);
+    if (kXupd) xu2 = load_pair(xupd, k0 + 2);
     load_slab(k0 + 4, st2, rt2);
     __syncthreads();
 
@@ -1654,6 +1712,31 @@ __global__ __launch_bounds__(T, T == 512 ? 2 : 1) void spmv_sweep_kernel(
             acc0 += ra * za;
             acc1 += ra * ra;
             if (two) { acc0 += rb * zb; acc1 += rb * rb; }
+          } else if (MODE == 6) {
+            {
+              d2_t xv = xu0;
+              xv.x += acg * xa;
+              xv.y += acg * xb;
+              acc2 += xv.x * xv.x;
+              acc3 += xa * xa;
+              if (two) {
+                acc2 += xv.y * xv.y;
+                acc3 += xb * xb;
+                MK_SWEEP_ST(reinterpret_cast<d2_t *>(reinterpret_cast<char *>(xupd) + ((unsigned)g << 3)), xv);
+              } else {
+                *reinterpret_cast<double *>(reinterpret_cast<char *>(xupd) + ((unsigned)g << 3)) = xv.x;
+              }
+            }
+            double ra = ax0.x, rb = ax0.y;
+            if (extra) { ra -= acg * ex0.x; rb -= acg * ex0.y; }   // off-rank part of A p' first (the default step's order)
+            ra -= acg * s0;
+            rb -= acg * s1;
+            out.x = ra;
+            out.y = rb;
+            const double za = ra * alpha, zb = rb * alpha;   // z = zscale r (zscale = 1: exact)
+            acc0 += ra * za;
+            acc1 += ra * ra;
+            if (two) { acc0 += rb * zb; acc1 += rb * rb; }
           } else {
             out.x = s0;
             out.y = s1;
@@ -1663,8 +1746,9 @@ __global__ __launch_bounds__(T, T == 512 ? 2 : 1) void spmv_sweep_kernel(
           }
         }
         if (MODE != 3 && MODE != 5) {
-          if (two) MK_SWEEP_ST(reinterpret_cast<d2_t *>(reinterpret_cast<char *>(y) + ((unsigned)g << 3)), out);
-          else *reinterpret_cast<double *>(reinterpret_cast<char *>(y) + ((unsigned)g << 3)) = out.x;
+          double *dst = (MODE == 6) ? y2 : y;   // (MODE 6: y holds the new p, written by the window fill)
+          if (two) MK_SWEEP_ST(reinterpret_cast<d2_t *>(reinterpret_cast<char *>(dst) + ((unsigned)g << 3)), out);
+          else *reinterpret_cast<double *>(reinterpret_cast<char *>(dst) + ((unsigned)g << 3)) = out.x;
         }
       }
       // slab k+2 (loaded three steps ago) into the slot plane k-2 occupied; nobody reads that slot in this step
@@ -1673,7 +1757,7 @@ __global__ __launch_bounds__(T, T == 512 ? 2 : 1) void spmv_sweep_kernel(
       idr = load_ids(k + 3);
       if (aux) axr = load_pair(aux, k + 3);
       if (kExtra && extra) exr = load_extra(k + 3);
-      if (MODE == 4) xur = load_pair(xupd, k + 3);
+      if (kXupd) xur = load_pair(xupd, k + 3);
       load_slab(k + 5, st, rt);
       __syncthreads();
     };
@@ -1685,12 +1769,16 @@ __global__ __launch_bounds__(T, T == 512 ? 2 : 1) void spmv_sweep_kernel(
   }
   if (MODE != 0) {
     __syncthreads();
-    double w[3] = {acc0, acc1, acc2};
-    block_sum<3, T>(w, ring);
+    constexpr int NACC = (MODE == 6) ? 4 : 3;
+    double w[NACC];
+    w[0] = acc0; w[1] = acc1; w[2] = acc2;
+    if (MODE == 6) w[NACC - 1] = acc3;
+    block_sum<NACC, T>(w, ring);
     if (threadIdx.x == 0) {
       slab[0 * kSlabStride + blockIdx.x] = w[0];
       if (MODE != 2) slab[1 * kSlabStride + blockIdx.x] = w[1];
-      if (MODE == 4) slab[2 * kSlabStride + blockIdx.x] = w[2];
+      if (MODE == 4 || MODE == 6) slab[2 * kSlabStride + blockIdx.x] = w[2];
+      if (MODE == 6) slab[3 * kSlabStride + blockIdx.x] = w[NACC - 1];
     }
   }
 }
@@ -1721,7 +1809,8 @@ static int sweep_segments(const mk_matrix *A, int mode, const SweepArgs &S, int 
   static const int no_fit = getenv("MK_SWEEP_NO_FIT") ? atoi(getenv("MK_SWEEP_NO_FIT")) : 0;
   // Only the two CG sweeps (3 and 5 streams each) gain; SpMV+dot (x in, y out) measured 4-10 % SLOWER with the fit
   // (512^3 490 against 469 us, 27-point 256^3 159 against 144 us, banded 2^26 280 against 259 us).
-  if (env_nseg <= 0 && !no_fit && (mode == 4 || mode == 5)) {
+  static const int fit3 = getenv("MK_SWEEP_FIT3") ? atoi(getenv("MK_SWEEP_FIT3")) : 0;   // A/B: the dots-only sweep as one round too
+  if (env_nseg <= 0 && !no_fit && (mode == 4 || mode == 5 || mode == 6 || (mode == 3 && fit3))) {
     const int64_t fit = (int64_t)c.num_cus * std::max(1, 1024 / S.C);
     const int64_t k = fit / S.ncp;
     if (k >= 1 && k * S.ncp * 10 >= fit * 9 && S.K / k >= 8) nseg = (int)k;
@@ -1739,7 +1828,7 @@ static int launch_sweep(const mk_matrix *A, double alpha, const double *x, doubl
                         const int *done, int *nblocks, const double *rhs = nullptr, const double *extra = nullptr,
                         PcgState *st = nullptr, const double *slab_in = nullptr, int nblocks_in = 0, int stride_in = kSlabStride,
                         double *xupd = nullptr, int flags = 0, double *norms = nullptr, int plane_begin = 0, int plane_end = 0,
-                        int max_blocks = kSlabStride) {
+                        int max_blocks = kSlabStride, double *y2 = nullptr, int gap0 = 0, int gap1 = 0) {
   Context &c = ctx();
   if (!A->sweep || A->sweep_streamed) return fail(MK_ERR_UNSUPPORTED, "spmv: the sweep kernel needs rows that are sub-lists of one (offsets, values) pattern with offsets a*P + b");
   SweepArgs S = *A->sweep;
@@ -1752,6 +1841,8 @@ static int launch_sweep(const mk_matrix *A, double alpha, const double *x, doubl
   const int nseg = sweep_segments(A, MODE, S, max_blocks);
   if (nseg < 1) return fail(MK_ERR_UNSUPPORTED, "spmv: sweep grid of %d chunks per plane does not fit %d reduction partials", S.ncp, max_blocks);
   S.nseg = nseg;
+  S.gap0 = gap0;
+  S.gap1 = gap1;
   const int blocks = (S.ncp * nseg + 7) / 8 * 8;
   if (nblocks) *nblocks = blocks;
   if (dry_launch()) return MK_OK;   // grid size only (mk_spmv_dot_static checks it against its scratch before anything is enqueued)
@@ -1768,7 +1859,7 @@ static int launch_sweep(const mk_matrix *A, double alpha, const double *x, doubl
     }                                                                                                                      \
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(TT), lds, c.stream, S, A->etab, A->nrows, A->ncols, A->pat,     \
                        A->pmask, A->npat, x, y, alpha, beta, slab, done, rhs, extra, st, slab_in, nblocks_in, stride_in,  \
-                       xupd, flags, norms, A->sweep_perm);                                                                 \
+                       xupd, flags, norms, A->sweep_perm, y2);                                                             \
   }
   if (T == 256 && nl == 2) MK_LAUNCH_SW(2, 256)
   else if (T == 256 && nl == 3) MK_LAUNCH_SW(3, 256)
@@ -2130,6 +2221,17 @@ int sweep_planes(const mk_matrix *A, int *rows_per_plane, int *nplanes) {
 
 int launch_sweep_cg_dots(const mk_matrix *A, const double *p, double *slab_out, PcgState *st, int *nblocks) {
   return launch_sweep<3>(A, 1.0, p, 0.0, nullptr, slab_out, nullptr, nblocks, nullptr, nullptr, st);
+}
+
+// single-reduction CG step (see MODE 6): sr_in = the five all-reduced values; extra (may be null) = off-rank part of A p'
+// over the local rows, zero on the ghost-free run [gap0, gap1)
+int launch_sweep_cg_single(const mk_matrix *A, const double *r_old, double *r_new, const double *p_old, double *p_new, double *x,
+                           double zscale, const double *extra, int gap0, int gap1, const double *sr_in, double *slab_out,
+                           PcgState *st, int two_norm, int rel_change, int first, int parity, double *norms, int *nblocks) {
+  if (r_old == r_new || p_old == p_new) return fail(MK_ERR_INVALID, "single-reduction CG step: r and p are read through other blocks' windows and cannot be updated in place");
+  return launch_sweep<6>(A, zscale, p_old, 0.0, p_new, slab_out, nullptr, nblocks, r_old, extra, st, sr_in, 1, 1, x,
+                         (two_norm ? 1 : 0) | (rel_change ? 2 : 0) | (first ? 4 : 0) | ((parity & 1) << 3), norms, 0, 0, kSlabStride, r_new,
+                         (gap0 + 1) & ~1, gap1);
 }
 
 int sweep_uniform_diag(const mk_matrix *A, double *inv_diag) {

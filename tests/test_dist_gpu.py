@@ -178,6 +178,82 @@ def test_dist_pcg_fused_sweep_step(world, precond):
     assert np.allclose(np.concatenate([x.get() for x in xs2]), o2["x"], rtol=1e-9, atol=1e-13)
 
 
+@pytest.mark.parametrize("kind,dims,world,precond", [(7, (32, 16, 24), 1, 0), (7, (32, 16, 24), 2, 1), (7, (32, 16, 24), 3, 0), (7, (32, 16, 24), 4, 1),
+                                                     (27, (16, 18, 24), 2, 0), (27, (16, 18, 24), 8, 1), (7, (64, 8, 33), 5, 0)])
+def test_dist_pcg_single_reduction_step(kind, dims, world, precond):
+    """mk_pcg_set_single_reduction: ONE all-reduce per iteration (alpha by the Chronopoulos-Gear identity, both halves of the
+    step in sweep MODE 6, r exchanged instead of p).  Same iterates as the two-reduction loop of hypre_PCGSolve in exact
+    arithmetic: iteration counts within 2, history to 1e-8, exact-k solutions to 1e-9 against orc_pcg; uneven slabs and an
+    odd number of planes included."""
+    rp, ci, v = oracle.stencil_csr(kind, *dims)
+    n = rp.size - 1
+    bh = np.random.default_rng(11 + world).normal(size=n)
+    o = oracle.pcg(rp, ci, v, bh, tol=1e-9, precond=precond, maxit=2000, want_norms=True)
+    rs = mkd.slab_row_start(*dims, world)
+    comms = mkd.Comm.local_world(world) if world > 1 else [None]
+    As = _blocks(rp, ci, v, n, rs, comms)
+    for A in As:
+        A.set_spmv_kernel(mk.SPMV_SWEEP)
+    bs = [A.vector(values=bh[rs[k]:rs[k + 1]]) for k, A in enumerate(As)]
+    for check_every in (9, 1):
+        xs = [A.vector(fill=0.0) for A in As]
+        Ss = [mk.PCG(max_iter=2000, tol=1e-9, precond=precond, logging=1, check_every=check_every) for _ in As]
+        for S in Ss:
+            S.set_single_reduction(True)
+        res = mkd.dist_pcg_solve(Ss, As, bs, xs)
+        assert all(S.single_reduction_used() for S in Ss)
+        assert all(q == res[0] for q in res)
+        assert res[0]["converged"] == 1 and abs(res[0]["iterations"] - o["iterations"]) <= 2
+        xg = np.concatenate([x.get() for x in xs])
+        assert np.linalg.norm(xg - o["x"]) <= 1e-6 * np.linalg.norm(o["x"])
+        assert np.linalg.norm(bh - oracle.csr_spmv(rp, ci, v, xg)) <= 1.5e-9 * np.linalg.norm(bh)
+        hist = Ss[0].residual_history(4000)
+        assert hist.size == res[0]["iterations"] + 1
+        m = min(hist.size, o["rel_norms"].size)
+        assert np.allclose(hist[:m], o["rel_norms"][:m], rtol=1e-8)
+        assert abs(res[0]["rel_res_norm"] - hist[-1]) <= 1e-14
+    # exactly k iterations
+    for k in (1, 4):
+        xs2 = [A.vector(fill=0.0) for A in As]
+        S2 = [mk.PCG(max_iter=k, tol=1e-30, precond=precond) for _ in As]
+        for S in S2:
+            S.set_single_reduction(True)
+        r2 = mkd.dist_pcg_solve(S2, As, bs, xs2)
+        o2 = oracle.pcg(rp, ci, v, bh, tol=1e-30, precond=precond, maxit=k)
+        assert r2[0]["iterations"] == k and r2[0]["converged"] == 0
+        assert np.allclose(np.concatenate([x.get() for x in xs2]), o2["x"], rtol=1e-9, atol=1e-13)
+    # a nonzero initial guess and a second solve with the same objects (niter > 1 of solvers.c:753-754 re-solves from x)
+    x0 = np.random.default_rng(3).normal(size=n)
+    xs3 = [A.vector(values=x0[rs[k]:rs[k + 1]]) for k, A in enumerate(As)]
+    S3 = [mk.PCG(max_iter=2000, tol=1e-8, precond=precond) for _ in As]
+    for S in S3:
+        S.set_single_reduction(True)
+    r3 = mkd.dist_pcg_solve(S3, As, bs, xs3)
+    o3 = oracle.pcg(rp, ci, v, bh, tol=1e-8, precond=precond, maxit=2000, x0=x0)
+    assert r3[0]["converged"] == 1 and abs(r3[0]["iterations"] - o3["iterations"]) <= 2
+    r4 = mkd.dist_pcg_solve(S3, As, bs, xs3)
+    assert r4[0]["converged"] == 1 and r4[0]["iterations"] <= 3
+
+
+def test_dist_pcg_single_reduction_falls_back():
+    """variable coefficients (diag blocks not on the sweep kernel): the request is declined, the default step runs"""
+    dims = (32, 16, 24)
+    rp, ci, v = oracle.stencil_csr(7, *dims, scale_seed=4)
+    n = rp.size - 1
+    bh = np.random.default_rng(2).normal(size=n)
+    o = oracle.pcg(rp, ci, v, bh, tol=1e-9, precond=0, maxit=2000)
+    rs = mkd.slab_row_start(*dims, 2)
+    As = _blocks(rp, ci, v, n, rs, mkd.Comm.local_world(2))
+    bs = [A.vector(values=bh[rs[k]:rs[k + 1]]) for k, A in enumerate(As)]
+    xs = [A.vector(fill=0.0) for A in As]
+    Ss = [mk.PCG(max_iter=2000, tol=1e-9) for _ in As]
+    for S in Ss:
+        S.set_single_reduction(True)
+    res = mkd.dist_pcg_solve(Ss, As, bs, xs)
+    assert not any(S.single_reduction_used() for S in Ss)
+    assert res[0]["converged"] == 1 and abs(res[0]["iterations"] - o["iterations"]) <= 2
+
+
 @pytest.mark.parametrize("world,precond,sweep", [(2, 0, False), (2, 1, True), (4, 0, True), (4, 1, False), (8, 0, True), (8, 1, True)])
 def test_dist_27pt_rowblock_cg(world, precond, sweep):
     """BASELINE configs[3] scaled down: 27-point stencil, z-slab row blocks (solvers.c:214-281), CG.  The off-rank rows of

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Overhead of the row-block machinery on ONE GPU: CG on nx*ny*nz as a single matrix against the same
 problem cut into `world` z-slabs driven as a local world (device copies instead of RCCL).
-usage: dist_probe.py nx ny nz world [iters]"""
+usage: dist_probe.py nx ny nz world [iters]      MK_PROBE_SINGLE=1: also time the single-reduction step"""
 import os
 import sys
 import time
@@ -57,6 +57,17 @@ def dist(it):
 
 
 ms2 = timed(dist)
+ms3 = None
+if os.environ.get("MK_PROBE_SINGLE"):
+    def dist1(it):
+        for v in xs:
+            v.fill(0.0)
+        Ss = [mk.PCG(max_iter=it, tol=0.0, logging=0, check_every=50) for _ in As]
+        for S in Ss:
+            S.set_single_reduction(True)
+        mkd.dist_pcg_solve(Ss, As, bs, xs)
+        assert Ss[0].single_reduction_used()
+    ms3 = timed(dist1)
 del As, bs, xs, comms   # release device objects before the interpreter (and a profiler's exit hooks) tear down
 print(f"{nx}x{ny}x{nz}: single matrix {ms1:.3f} ms/iteration; {world} local ranks {ms2:.3f} ms/iteration "
-      f"({ms2 / world:.3f} ms per rank-iteration)", flush=True)
+      f"({ms2 / world:.3f} ms per rank-iteration)" + (f"; single-reduction step {ms3:.3f} ms/iteration ({ms3 / world:.3f} per rank-iteration)" if ms3 else ""), flush=True)
