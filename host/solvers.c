@@ -39,6 +39,8 @@ static double now_s(void) {
     }                                                                             \
   } while (0)
 
+static int g_single_reduction = 0;   /* -single_reduction: ask mk_dist_pcg_solve for one all-reduce per iteration */
+
 static void usage(const char *argv0) {
   printf("\nUsage: %s [<options>]\n\n", argv0);
   printf("  -mtx <matrix.mtx>      : matrix market path\n");
@@ -57,6 +59,7 @@ static void usage(const char *argv0) {
   printf("                           50 - PCG\n");
   printf("                           51 - PCG + diagonal scaling\n");
   printf("                           70 - Jacobi iteration\n");
+  printf("  -single_reduction      : row-block PCG (50, 51 with -np / -dist): one all-reduce per iteration instead of two\n");
   printf("  -p <file>              : append the board power in watts to <file>, 10 samples a second, while the solver runs\n");
   printf("  -id <device>           : GPU whose power is sampled (default: the one in use)\n");
   printf("  -np <N> -rank <r>      : N processes, one GPU each, solve one system over nnz-balanced row blocks\n");
@@ -267,11 +270,17 @@ static int run_distributed(const char *mtx, const char *bfile, const char *xfile
     CK(mk_pcg_set_print_level(solver, rank == 0 ? prnt_info : 0));      /* :742 */
     CK(mk_pcg_set_logging(solver, 1));                                  /* :744 */
     if (solver_id == 51) CK(mk_pcg_set_precond(solver, MK_PRECOND_JACOBI));
+    if (g_single_reduction) CK(mk_pcg_set_single_reduction(solver, 1));
     CK(mk_synchronize());
     double t = -now_s();                                                /* :752 */
     for (int i = 0; i < niter; i++) CK(mk_dist_pcg_solve(1, &solver, &A, &b, &x));   /* :747-754 */
     CK(mk_synchronize());
     walltime = t + now_s();                                             /* :755 */
+    if (g_single_reduction && rank == 0) {
+      int used = 0;
+      CK(mk_pcg_get_single_reduction(solver, &used));
+      printf("CG step = %s\n", used ? "single reduction per iteration" : "two reductions per iteration (single-reduction step declined: a rank's diagonal block is not on the sweep kernel)");
+    }
     CK(mk_pcg_get_num_iterations(solver, &num_iterations));             /* :765 */
     CK(mk_pcg_get_final_relative_residual_norm(solver, &final_res_norm)); /* :766 */
     CK(mk_pcg_destroy(solver));                                         /* :775 */
@@ -328,6 +337,7 @@ int main(int argc, char *argv[]) {
     else if (!strcmp(a, "-rank") && has) { rank = atoi(argv[i + 1]); i += 2; }
     else if (!strcmp(a, "-id_file") && has) { id_file = argv[i + 1]; i += 2; }
     else if (!strcmp(a, "-dist")) { force_dist = 1; i += 1; }
+    else if (!strcmp(a, "-single_reduction")) { g_single_reduction = 1; i += 1; }
     else if (!strcmp(a, "-help")) { usage(argv[0]); return 0; }
     else i += 1;                                                      /* unknown flags are skipped (:149-151) */
   }

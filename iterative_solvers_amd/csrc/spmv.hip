@@ -375,7 +375,8 @@ static int plan_sweep(mk_matrix *A, const std::vector<int> &tab, const std::vect
   for (int q = 0; q < npat && all_have; q++) all_have = (mask[q] >> S.diag) & 1u;
   A->sweep_diag_uniform = all_have;
   // default only when the grid can fill the chip: ncp chunks per plane times segments of >= 8 planes
-  A->sweep_auto = (int64_t)S.ncp * std::max(1, S.K / 8) >= 2 * (int64_t)ctx().num_cus;
+  static const int env_min = getenv("MK_SWEEP_AUTO_MIN") ? atoi(getenv("MK_SWEEP_AUTO_MIN")) : 0;   // tests: smaller grids take the sweep kernel too
+  A->sweep_auto = (int64_t)S.ncp * std::max(1, S.K / 8) >= (env_min > 0 ? (int64_t)env_min : 2 * (int64_t)ctx().num_cus);
   return MK_OK;
 }
 

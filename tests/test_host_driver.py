@@ -444,6 +444,27 @@ def test_driver_row_block_path_one_rank(tmp_path, solver, precond):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("solver,precond,dims,auto_min", [(50, 0, (256, 200), "1"), (51, 1, (256, 200), "1"), (51, 1, (56, 40), None)])
+def test_driver_single_reduction_flag(tmp_path, solver, precond, dims, auto_min):
+    """`solver -dist -single_reduction`: mk_pcg_set_single_reduction behind the driver; with the diag block on the sweep kernel
+    (MK_SWEEP_AUTO_MIN=1: grids this small would take the pattern kernel) the step is taken, else declined and the default
+    step runs: same answer either way"""
+    mtx = tmp_path / "poisson.mtx"
+    rp, ci, v = _write_poisson(mtx, *dims)
+    o = oracle.pcg(rp, ci, v, np.ones(rp.size - 1), tol=1e-8, precond=precond, maxit=3000)
+    out = subprocess.run([os.path.join(HOST, "solver"), "-solver", str(solver), "-mtx", str(mtx), "-tol", "1e-8", "-maxit", "3000",
+                          "-log", "0", "-dist", "-single_reduction", "-id_file", str(tmp_path / "id.bin")],
+                         capture_output=True, text=True, timeout=180, cwd=tmp_path,
+                         env=dict(os.environ, **({"MK_SWEEP_AUTO_MIN": auto_min} if auto_min else {})))
+    assert out.returncode == 0, out.stderr
+    m = re.search(r"^CG step = (single|two) reduction", out.stdout, re.M)
+    assert m and (m.group(1) == "single") == (auto_min is not None), out.stdout
+    it = int(re.search(r"^Iterations = (\d+)$", out.stdout, re.M).group(1))
+    nrm = float(re.search(r"^Final Relative Residual Norm = ([0-9.e+-]+)$", out.stdout, re.M).group(1))
+    assert abs(it - o["iterations"]) <= 2 and nrm < 1e-8
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("solver,label", [(6, "ParCSRBiCGSTABC"), (12, "GMRES"), (40, "CGNR")])
 def test_driver_row_block_path_one_rank_other_krylov_solvers(tmp_path, solver, label):
     """`solver -dist -solver 6|12|40`: mk_dist_bicgstab_solve / mk_dist_gmres_solve / mk_dist_cgnr_solve behind the np > 1 code
