@@ -153,7 +153,8 @@ int mk_pcg_solve(mk_pcg *S, const mk_matrix *A, const mk_vector *b, mk_vector *x
   // Variable-coefficient grids (vsweep kernel): K1 and K2 stay (the values cannot be streamed twice), K3 rides in K1's
   // window fill from the second iteration on: p' = z + beta p goes to the other p buffer while the window is loaded.
   // 12 nnz + 86 n bytes of the CSR model's 12 nnz + 92 n, and one launch less.
-  const bool vfuse = (A->kernel == MK_SPMV_VSWEEP) && !no_fused && !no_pfuse && S->p2 != nullptr;
+  // (rows of more than 8 entries -- one row per lane, SweepArgs.rpl == 1 -- keep K1 + K2 + K3: vsweep.hip launch_vsweep_m)
+  const bool vfuse = (A->kernel == MK_SPMV_VSWEEP) && !no_fused && !no_pfuse && S->p2 != nullptr && A->sweep && A->sweep->rpl != 1;
   if (vfuse) palt = S->p2;
   // ... and the solution update rides there as well, one kernel late (x += alpha p while the fill has p in registers):
   // K2 then streams s and r only.  12 nnz + 78 n bytes.  The update of the last completed step is applied after the loop.

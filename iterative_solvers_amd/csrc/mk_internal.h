@@ -92,6 +92,7 @@ struct SweepArgs {
   int diag;       // index of the last entry with offset 0, or -1
   double dv;      // its value
   int gap0, gap1; // MODE 6: local rows [gap0, gap1) have a zero `extra` (set per launch)
+  int rpl;        // vsweep kernel: rows per lane (2; 1 = long rows: C = T = 512, one block per CU)
 };
 struct SweepEntry {   // one entry of the base pattern.  Device table: 4 copies x 32 entries (padded with zeros);
   int off;            // copy c serves the steps whose plane sits in ring slot c: off = byte offset in the LDS ring

@@ -242,6 +242,7 @@ static int plan_sweep(mk_matrix *A, const std::vector<int> &tab, const std::vect
   int ea[32] = {0}, eb[32] = {0};
   double ev[32] = {0.0};
   S.len = len;
+  S.rpl = 2;
   int maxabs = 0;
   for (int u = 0; u < len; u++) maxabs = std::max(maxabs, std::abs(off_of(base, u)));
   // streamed values leave less LDS for the window: offsets beyond 256 are taken as plane offsets there
@@ -298,7 +299,26 @@ static int plan_sweep(mk_matrix *A, const std::vector<int> &tab, const std::vect
     };
     // measured (7-pt, product + dots): 512^3 C = 1024 1.955 ms / C = 512 2.05 ms; 256^3 (64 chunks of 1024 per plane)
     // 0.260 / 0.249 ms: the long chunk (window 2x instead of 3x the chunk) wins once a plane fills the chip with them
-    if ((env_vc == 512 || env_vc == 1024) && fits(env_vc)) S.C = env_vc;
+    // rows of 9 to 28 entries (27-point operators): one row per lane, the stage holds exactly len * C values, the ring three
+    // slabs.  Chunks of 512 rows, one block of 8 waves per CU (27 points on 512-wide planes: 110.6 + 37 KB), when that fits;
+    // else chunks of 256 rows (wider planes).  Measured, 27-point 256^3, product + dots: C = 512 0.815 ms, C = 256 (two
+    // blocks per CU) 0.825 ms, stream kernel 0.896 ms.
+    auto lds_long = [&](int C) { return (size_t)3 * (C + halo) * 8 + ((size_t)len * C + 8) * 8 + (size_t)npat * 4; };
+    static const int no_long = getenv("MK_NO_VSWEEP_LONG") ? atoi(getenv("MK_NO_VSWEEP_LONG")) : 0;
+    static const int env_lc = getenv("MK_VSWEEP_LONG_C") ? atoi(getenv("MK_VSWEEP_LONG_C")) : 0;   // A/B: 256 or 512
+    if (len > 8) {
+      if (no_long || len > 28 || A->nnz >= ((int64_t)1 << 31) - 65536) return MK_OK;
+      const bool ok256 = 256 + halo <= 1536 && lds_long(256) <= 160 * 1024 - 1024;
+      const bool two256 = 256 + halo <= 1536 && 2 * (lds_long(256) + 512) <= 160 * 1024;
+      const bool ok512 = 512 + halo <= 2048 && lds_long(512) <= 160 * 1024 - 1024;
+      if (env_lc == 256 && ok256) S.C = 256;
+      else if (env_lc == 512 && ok512) S.C = 512;
+      else if (ok512) S.C = 512;
+      else if (two256 || ok256) S.C = 256;
+      else return MK_OK;
+      S.rpl = 1;
+    }
+    else if ((env_vc == 512 || env_vc == 1024) && fits(env_vc)) S.C = env_vc;
     else if (fits(1024) && S.P / 1024 >= ctx().num_cus && halo >= 512) S.C = 1024;
     else if (fits(512)) S.C = 512;
     else if (fits(1024)) S.C = 1024;
@@ -325,7 +345,8 @@ static int plan_sweep(mk_matrix *A, const std::vector<int> &tab, const std::vect
   memset(E, 0, sizeof(E));
   for (int c4 = 0; c4 < 4; c4++)
     for (int u = 0; u < len; u++) {
-      const int slot0 = ((c4 + ea[u]) & 3) * S.sw, q = S.wlo + eb[u];
+      // (long-row plans of the vsweep kernel run a ring of three slabs)
+      const int slot0 = (S.rpl == 1 ? (c4 + ea[u] + 3) % 3 : ((c4 + ea[u]) & 3)) * S.sw, q = S.wlo + eb[u];
       if (with_values) {
         // spmv_sweep_kernel keeps a slab de-interleaved (even window entries in the first half, odd in the second, see
         // write_slab): off = where the lane finds the operand of its first row, off1 = of its second row
@@ -377,6 +398,9 @@ static int plan_sweep(mk_matrix *A, const std::vector<int> &tab, const std::vect
   // default only when the grid can fill the chip: ncp chunks per plane times segments of >= 8 planes
   static const int env_min = getenv("MK_SWEEP_AUTO_MIN") ? atoi(getenv("MK_SWEEP_AUTO_MIN")) : 0;   // tests: smaller grids take the sweep kernel too
   A->sweep_auto = (int64_t)S.ncp * std::max(1, S.K / 8) >= (env_min > 0 ? (int64_t)env_min : 2 * (int64_t)ctx().num_cus);
+  // long rows on the vsweep kernel: one block per CU, so the grid must be large for its prologues to vanish (27-point 128^3:
+  // 0.136 ms against 0.115 ms on the stream kernel; 256^3: 0.815 against 0.896 ms)
+  if (S.rpl == 1 && env_min <= 0 && A->nrows < 6 * 1000 * 1000) A->sweep_auto = false;
   return MK_OK;
 }
 
@@ -2391,7 +2415,7 @@ int mk_matrix_set_spmv_kernel(mk_matrix *A, int kernel, int lanes_per_row) {
     return fail(MK_ERR_UNSUPPORTED, "mk_matrix_set_spmv_kernel: the rows of this matrix are not sub-lists of one grid pattern with shared values");
   if (kernel == MK_SPMV_VSWEEP && (!A->sweep || !A->sweep_streamed))
     return fail(MK_ERR_UNSUPPORTED, "mk_matrix_set_spmv_kernel: MK_SPMV_VSWEEP serves matrices whose rows are sub-lists (by column offset) of one grid "
-                                    "pattern of at most 8 entries and do not share their values (constant coefficients: MK_SPMV_SWEEP)");
+                                    "pattern of at most 28 entries and do not share their values (constant coefficients: MK_SPMV_SWEEP)");
   if (kernel == MK_SPMV_PATTERN && !A->vtab)
     return fail(MK_ERR_UNSUPPORTED, "mk_matrix_set_spmv_kernel: the rows of this matrix do not share (offsets, values) patterns");
   if (lanes_per_row != 0) {

@@ -54,7 +54,12 @@ __device__ __forceinline__ d2u_t vs_ld_u(const d2u_t *ptr) {   // keeps the 8-by
 //   (hypre's rel_change test needs it); K2 then no longer reads p or touches x: 8 B per row less.
 // NL = 16-byte ring loads per thread per slab = ceil(sw / 2T); NVL = 16-byte value loads per thread per plane-step
 // (NVL * 2T >= len * C entries).
-template <int MODE, int NL, int NVL, int T, bool NT, bool PRE>
+// RPL = rows per lane.  2: rows of at most 8 entries (C = 2T rows per chunk, the values of three plane-steps in flight in
+// registers).  1: LONG rows, up to 28 entries (27-point operators: 216 B of values per row): C = T = 512 rows per chunk, one
+// block of 8 waves per CU whose stage holds len * 512 values (110 KB for 27 points) beside the window ring, ONE plane-step
+// of values in flight in registers (a step of 512 long rows outlasts the memory latency several times over).  Same order
+// of operations per row either way.
+template <int MODE, int NL, int NVL, int T, bool NT, bool PRE, int RPL = 2>
 __global__ __launch_bounds__(T, 2) void spmv_vsweep_kernel(
     const SweepArgs S, const SweepEntry *__restrict__ etab, int64_t nrows, int64_t ncols, int64_t nnz,
     const unsigned short *__restrict__ pat, const unsigned *__restrict__ pmask, int npat, const int *__restrict__ rowptr,
@@ -64,11 +69,20 @@ __global__ __launch_bounds__(T, 2) void spmv_vsweep_kernel(
     double *__restrict__ norms, double *__restrict__ xupd) {
   if (done != nullptr && *done != 0) return;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  constexpr int C = 2 * T, NS = kNS, VCAP = NVL * 2 * T;
+  // ring slots: planes k-1, k, k+1 and the one being written -- which, with this kernel's two barriers per step, may be the
+  // slot plane k-1 leaves (the write sits between the barriers, when nobody reads): long rows take three slots and give
+  // the LDS to the value stage
+  constexpr int C = RPL * T, NS = (RPL == 1) ? 3 : kNS, VCAP = NVL * 2 * T;
+  // register stages of values: three plane-steps ahead for short rows; long rows two (a plane-step of 512 rows x 27 values is
+  // 110 KB per CU), re-loaded during the products (ILV below)
+  constexpr int VST = (RPL == 1) ? 2 : 3;
   const int sw = S.sw;
+  // entries of the value stage: what the loads cover (RPL 2), or exactly one plane-step of the chunk's values (RPL 1: the
+  // last pieces of the last load fall behind it and are not written -- the stage fills the LDS to the last KB)
+  const int vcap = (RPL == 1) ? ((S.len * C + 1) & ~1) : VCAP;
   double *ring = reinterpret_cast<double *>(smem_raw);          // NS slabs of sw entries
-  double *sval = ring + NS * sw;                                 // VCAP + 8 entries: the values of one plane-step
-  unsigned *smask = reinterpret_cast<unsigned *>(sval + VCAP + 8);   // npat
+  double *sval = ring + NS * sw;                                 // vcap + 8 entries: the values of one plane-step
+  unsigned *smask = reinterpret_cast<unsigned *>(sval + vcap + 8);   // npat
   const int tid = threadIdx.x;
   if (MODE == 3) {   // K3's prologue (krylov_kernels.h pcg_update_p_kernel), every block the same bits
     if (block_flag_raised(&st->done)) return;
@@ -108,30 +122,31 @@ __global__ __launch_bounds__(T, 2) void spmv_vsweep_kernel(
     const int k0 = (int)((int64_t)seg * S.K / S.nseg), k1 = (int)((int64_t)(seg + 1) * S.K / S.nseg);
     const int r0 = cp * C;
     const int rows_here = min(C, S.P - r0);
-    const int lr = 2 * tid;
+    const int lr = RPL * tid;   // the lane's row(s) in the chunk
+    const int lw = 2 * tid;     // its place in the window fill (two entries per 16-byte piece, pieces 2T apart)
     // every load that runs ahead is unconditional, with its address clamped into the arrays (see spmv_sweep_kernel)
     const int xlast = ((int)ncols - 1) & ~1;
-    const int rlast = (nr - 1) & ~1;
+    const int rlast = (RPL == 2) ? ((nr - 1) & ~1) : nr - 1;
     const int elast = (int)max((int64_t)0, nnz - 1);   // val[elast + 1] is allocation slack (dev_alloc): never used by a row
 
-    // the one window piece of this lane that holds rows of the block's own chunk (pieces lie C = 2 T apart), and its offset
+    // the one window piece of this lane that holds rows of the block's own chunk (pieces lie 2 T >= C apart), and its offset
     // in the chunk: the rows whose p' the lane stores and, with xupd, whose solution entries it updates
     int oi = -1, ownoff = 0;
 #pragma unroll
     for (int i = 0; i < NL; i++) {
-      const int own = lr + i * 2 * T - S.wlo;
-      if (own >= 0 && own < rows_here && lr + i * 2 * T < sw) { oi = i; ownoff = own; }
+      const int own = lw + i * 2 * T - S.wlo;
+      if (own >= 0 && own < rows_here && lw + i * 2 * T < sw) { oi = i; ownoff = own; }
     }
     const bool defx = (MODE == 3) && xupd != nullptr;
     auto load_x = [&](int j) -> d2_t {
-      const int g = min(max(min(j, k1) * S.P + r0 + ownoff, 0), rlast);   // (plane k0 - 1 of the first segment lies before the array)
+      const int g = min(max(min(j, k1) * S.P + r0 + ownoff, 0), (nr - 1) & ~1);   // (plane k0 - 1 of the first segment lies before the array)
       return vs_ld<NT>(reinterpret_cast<const d2_t *>(reinterpret_cast<const char *>(xupd) + ((unsigned)g << 3)));
     };
     constexpr int NLR = (MODE == 3) ? NL : 1;              // second window stream (the residual) only in MODE 3
     constexpr int NLD = (MODE == 3 && PRE) ? NL : 1;       // third (1/diag per row) with the Jacobi preconditioner
     auto load_slab = [&](int j, d2_t(&reg)[NL], d2_t(&regr)[NLR], d2_t(&regd)[NLD], d2_t &regx) {   // window of plane j
       if (defx) regx = load_x(j);
-      const int g0 = min(j, k1) * S.P + r0 - S.wlo + lr;
+      const int g0 = min(j, k1) * S.P + r0 - S.wlo + lw;
 #pragma unroll
       for (int i = 0; i < NL; i++) {
         const int g = min(max(g0 + i * 2 * T, 0), xlast);
@@ -141,10 +156,10 @@ __global__ __launch_bounds__(T, 2) void spmv_vsweep_kernel(
       }
     };
     auto write_slab = [&](int slot, int j, const d2_t(&reg)[NL], const d2_t(&regr)[NLR], const d2_t(&regd)[NLD], const d2_t &regx) {
-      double *dst = ring + slot * sw + lr;
+      double *dst = ring + slot * sw + lw;
 #pragma unroll
       for (int i = 0; i < NL; i++) {
-        const int wi = lr + i * 2 * T;   // position in the window
+        const int wi = lw + i * 2 * T;   // position in the window
         if (wi < sw) {
           d2_t v = reg[i];
           if (MODE == 3) {
@@ -191,31 +206,42 @@ __global__ __launch_bounds__(T, 2) void spmv_vsweep_kernel(
     // 64-bit reads collide two ways (measured: bank-conflict cycles were 70 % of the LDS busy cycles); flipping the low
     // bit in every other block of 32 entries makes the 32 lanes of a pass hit 32 different bank pairs for len 3, 5, 7.
     // A thread's write positions 2 (tid + i T) all have bit 5 = bit 4 of tid: it swaps its pairs or never does.
-    const bool swp = (tid >> 4) & 1;
+    // (Only for even strides: with one row per lane and 27 entries per row the stride is odd, 16 lanes already hit 16 different
+    // bank pairs, and flipping bit 0 of some of them would create the two-way conflicts the swizzle is there to remove.)
+    const int swm = ((RPL * S.len) & 1) ? 0 : 1;
+    const bool swp = swm && ((tid >> 4) & 1);
     auto write_vals = [&](const d2u_t(&reg)[NVL]) {
 #pragma unroll
       for (int i = 0; i < NVL; i++) {
         d2_t v;
         v.x = swp ? reg[i].y : reg[i].x;
         v.y = swp ? reg[i].x : reg[i].y;
-        *reinterpret_cast<d2_t *>(sval + 2 * (tid + i * T)) = v;
+        if (RPL == 2 || 2 * (tid + i * T) < vcap) *reinterpret_cast<d2_t *>(sval + 2 * (tid + i * T)) = v;
       }
     };
-    auto stage_at = [&](int idx) -> double { return sval[idx ^ ((idx >> 5) & 1)]; };
+    auto stage_at = [&](int idx) -> double { return sval[idx ^ ((idx >> 5) & swm)]; };
     auto row_of = [&](int j) -> int { return j * S.P + r0 + lr; };
     auto live = [&](int j) -> bool { return j < k1 && lr < rows_here && row_of(j) < nr; };
     auto load_ids = [&](int j) -> unsigned {   // pattern ids of rows g, g+1 (g even); the id behind the last row is slack
       const int g = min(row_of(j), rlast);
+      if (RPL == 1) return (unsigned)vs_ld<NT>(reinterpret_cast<const unsigned short *>(reinterpret_cast<const char *>(pat) + ((unsigned)g << 1)));
       return vs_ld<NT>(reinterpret_cast<const unsigned *>(reinterpret_cast<const char *>(pat) + ((unsigned)g << 1)));
     };
     // first value of the lane's row pair: rowpair[g / 2] = rowptr[g] (g even), 2 B per row instead of 4; the second row's values
     // follow the first row's, whose length is the popcount of its mask
     auto load_rp = [&](int j) -> int {
       const int g = min(row_of(j), rlast);
+      if (RPL == 1) return vs_ld<NT>(reinterpret_cast<const int *>(reinterpret_cast<const char *>(rowptr) + ((unsigned)g << 2)));   // (4 B per row of 200)
       return vs_ld<NT>(reinterpret_cast<const int *>(reinterpret_cast<const char *>(rowpair) + ((unsigned)g << 1)));
     };
     auto load_pair = [&](const double *p, int j) -> d2_t {
       const int g = min(row_of(j), rlast);
+      if (RPL == 1) {
+        d2_t v;
+        v.x = vs_ld<NT>(reinterpret_cast<const double *>(reinterpret_cast<const char *>(p) + ((unsigned)g << 3)));
+        v.y = 0.0;
+        return v;
+      }
       return vs_ld<NT>(reinterpret_cast<const d2_t *>(reinterpret_cast<const char *>(p) + ((unsigned)g << 3)));
     };
     const double *aux = (MODE == 2) ? rhs : (MODE == 0 && beta != 0.0) ? y : nullptr;
@@ -225,7 +251,8 @@ __global__ __launch_bounds__(T, 2) void spmv_vsweep_kernel(
     // values of plane k+1 at step k, is written to LDS behind the step's first barrier and re-loaded with plane k+4
     d2_t st0[NL], st1[NL], st2[NL], rt0[NLR], rt1[NLR], rt2[NLR], dt0[NLD], dt1[NLD], dt2[NLD];
     d2_t xt0 = {0.0, 0.0}, xt1 = xt0, xt2 = xt0;
-    d2u_t vs0[NVL], vs1[NVL], vs2[NVL];
+    constexpr int NV1 = (VST >= 2) ? NVL : 1, NV2 = (VST == 3) ? NVL : 1;   // (stages the variant does not have shrink to one register)
+    d2u_t vs0[NVL], vs1[NV1], vs2[NV2];
     int vb0 = span_begin(k0), vb1 = span_begin(k0 + 1), vb2 = span_begin(k0 + 2);
     load_slab(k0 - 1, st0, rt0, dt0, xt0);
     load_slab(k0, st1, rt1, dt1, xt1);
@@ -236,11 +263,22 @@ __global__ __launch_bounds__(T, 2) void spmv_vsweep_kernel(
     write_slab(2, k0 + 1, st2, rt2, dt2, xt2);
     write_vals(vs0);
     int vbcur = vb0;                // span begin of the plane whose values sit in LDS
-    load_vals(vb1, vs1);
-    load_vals(vb2, vs2);
-    vb0 = span_begin(k0 + 3);
-    load_vals(vb0, vs0);
-    int vbn = span_begin(k0 + 4);   // begin of the span loaded next (plane k+4 at step k), fetched one step early
+    int vbn;                        // begin of the span loaded next (plane k + VST + 1 at step k), fetched one step early
+    if constexpr (VST == 3) {
+      load_vals(vb1, reinterpret_cast<d2u_t(&)[NVL]>(vs1));
+      load_vals(vb2, reinterpret_cast<d2u_t(&)[NVL]>(vs2));
+      vb0 = span_begin(k0 + 3);
+      load_vals(vb0, vs0);
+      vbn = span_begin(k0 + 4);
+    } else if constexpr (VST == 2) {
+      vb0 = vb1;                    // stage 0: plane k0 + 1; stage 1 is loaded with plane k0 + 2 during the first step's products
+      load_vals(vb0, vs0);
+      vbn = vb2;
+    } else {
+      vb0 = vb1;                    // the one stage holds plane k0 + 1 now
+      load_vals(vb0, vs0);
+      vbn = vb2;
+    }
     d2_t ax0 = {0.0, 0.0}, ax1 = ax0, ax2 = ax0, ex0 = ax0, ex1 = ax0, ex2 = ax0;
     unsigned id0 = load_ids(k0);
     int rp0 = load_rp(k0);
@@ -261,26 +299,53 @@ __global__ __launch_bounds__(T, 2) void spmv_vsweep_kernel(
 
     // vbcur: span begin of plane k (its values are in sval now).  vsn / vbs: value stage of plane k+1 and its span begin,
     // re-loaded with plane k+4 whose span begin is vbn (fetched during the previous step).
-    auto step = [&](int k, d2_t(&st)[NL], d2_t(&rt)[NLR], d2_t(&dt)[NLD], d2_t &xt, unsigned &idr, int &rpr, d2_t &axr, d2_t &exr, d2u_t(&vsn)[NVL], int &vbs) {
+    // s3 = (k - k0) mod 3, a constant at every call (the loops below advance by multiples of three)
+    // ILV (long rows, two value stages): the stage written to LDS in the step before (vso) is re-loaded DURING this step's
+    // products, a few loads in front of every batch of entries, instead of in one burst behind the LDS writes: a CU keeps only
+    // so many misses in flight, a burst of 14 loads per lane held all its waves in the issue until memory had taken most of
+    // them, and loads and products took turns (27-point 256^3: 0.60 ms without the products, 0.45 ms without the loads, 0.885 ms
+    // together).
+    constexpr bool ILV = (RPL == 1 && VST == 2);
+    constexpr int NB = ILV ? (2 * NVL + 7) / 8 : 1, QL = (NVL + NB - 1) / NB;
+    auto step = [&](int k, int s3, d2_t(&st)[NL], d2_t(&rt)[NLR], d2_t(&dt)[NLD], d2_t &xt, unsigned &idr, int &rpr, d2_t &axr, d2_t &exr, d2u_t(&vsn)[NVL], int &vbs,
+                    d2u_t(&vso)[NVL], int &vbo) {
       const int vbk = vbcur;
       const unsigned idc = idr;
       const int rpc = rpr;
       const d2_t axc = axr, exc = exr;
-      const int jb = (k - k0 + 1) & (NS - 1);   // ring slot of plane k
-      if (live(k)) {
+      const int jb = (NS == 4) ? ((k - k0 + 1) & 3) : (s3 + 1) % 3;   // ring slot of plane k
+      const bool is_live = live(k);
+      {
         const int g = row_of(k);
-        const bool two = g + 1 < nr;
-        const unsigned mA = smask[idc & 0xffffu];
+        const bool two = (RPL == 2) && g + 1 < nr;
+        const unsigned mA = smask[min(idc & 0xffffu, (unsigned)npat - 1u)];
         const unsigned mB = two ? smask[min(idc >> 16, (unsigned)npat - 1u)] : 0u;
         const char *wl = reinterpret_cast<const char *>(ring) + lr * 8;
         // positions of the two rows' first values in the stage; a row without a live partner reads its own
         const int vA = rpc - vbk;
         const int vB = two ? vA + __popc(mA) : vA;
         double s0 = 0.0, s1 = 0.0;
-        for (int u0 = 0; u0 < S.len; u0 += 8) {
+        // long rows: a wave whose rows all hold the whole base pattern (every wave away from the grid's faces) finds entry u
+        // of a row at u -- no population counts, no selects; same products added in the same order
+        const unsigned fullm = S.len >= 32 ? 0xffffffffu : (1u << S.len) - 1u;
+        const bool wave_full = (RPL == 1) && __all(!is_live || mA == fullm);
+        auto batch = [&](int u0) {
           typedef int i16_t __attribute__((ext_vector_type(16)));
           const i16_t *eb = reinterpret_cast<const i16_t *>(etab + jb * 32 + u0);
           const i16_t b0 = eb[0], b1 = eb[1];
+          if (RPL == 1 && wave_full) {
+            const int offf[8] = {b0[0], b0[4], b0[8], b0[12], b1[0], b1[4], b1[8], b1[12]};
+            double pf[8], cf[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+              pf[u] = *reinterpret_cast<const double *>(wl + offf[u]);
+              cf[u] = stage_at(vA + u0 + u);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+              if (u0 + u < S.len) s0 = s0 + cf[u] * pf[u];
+            return;
+          }
           const int off[8] = {b0[0], b0[4], b0[8], b0[12], b1[0], b1[4], b1[8], b1[12]};
           const unsigned ka = mA >> u0, kb = mB >> u0;
           const int va0 = vA + __popc(mA & ((1u << u0) - 1u));
@@ -290,32 +355,53 @@ __global__ __launch_bounds__(T, 2) void spmv_vsweep_kernel(
           for (int u = 0; u < 8; u++) {
             const double *w = reinterpret_cast<const double *>(wl + off[u]);
             p0[u] = w[0];
-            p1[u] = w[1];
+            if (RPL == 2) p1[u] = w[1];
             // the u-th entry of the base pattern is the row's (number of earlier entries it has)-th value
             c0[u] = stage_at(va0 + __popc(ka & ((1u << u) - 1u)));
-            c1[u] = stage_at(vb0p + __popc(kb & ((1u << u) - 1u)));
+            if (RPL == 2) c1[u] = stage_at(vb0p + __popc(kb & ((1u << u) - 1u)));
           }
 #pragma unroll
           for (int u = 0; u < 8; u++) {
-            const double t0 = s0 + c0[u] * p0[u], t1 = s1 + c1[u] * p1[u];
+            const double t0 = s0 + c0[u] * p0[u];
             s0 = ((ka >> u) & 1u) ? t0 : s0;
-            s1 = ((kb >> u) & 1u) ? t1 : s1;
+            if (RPL == 2) {
+              const double t1 = s1 + c1[u] * p1[u];
+              s1 = ((kb >> u) & 1u) ? t1 : s1;
+            }
           }
+        };
+        if constexpr (ILV) {
+          const int vbnew = vbn;   // span begin of plane k + 2 (fetched during the step before)
+#pragma unroll
+          for (int b = 0; b < NB; b++) {
+#pragma unroll
+            for (int i = b * QL; i < (b + 1) * QL; i++)
+              if (i < NVL) {
+                const int e = min(vbnew + 2 * (tid + i * T), elast);
+                vso[i] = vs_ld_u<NT>(reinterpret_cast<const d2u_t *>(reinterpret_cast<const char *>(val) + ((size_t)(unsigned)e << 3)));
+              }
+            if (is_live && b * 8 < S.len) batch(b * 8);
+          }
+          vbo = vbnew;
+        } else {
+          if (is_live)
+            for (int u0 = 0; u0 < S.len; u0 += 8) batch(u0);
         }
+        if (is_live) {
         d2_t out;
         if (MODE == 0) {
           out.x = (beta == 0.0) ? alpha * s0 : alpha * s0 + beta * axc.x;
           out.y = (beta == 0.0) ? alpha * s1 : alpha * s1 + beta * axc.y;
         } else {
           const double *wc = reinterpret_cast<const double *>(wl) + jb * sw + S.wlo;   // x[g], x[g+1]
-          const double xa = wc[0], xb = wc[1];
+          const double xa = wc[0], xb = (RPL == 2) ? wc[1] : 0.0;
           if (MODE == 2) {
             const double ra = (axc.x - exc.x) - s0, rb = (axc.y - exc.y) - s1;
             double da = 0.0, db = 0.0;
             if (S.diag >= 0) {
               const unsigned below = (1u << S.diag) - 1u;
               if ((mA >> S.diag) & 1u) da = stage_at(vA + __popc(mA & below));
-              if ((mB >> S.diag) & 1u) db = stage_at(vB + __popc(mB & below));
+              if (RPL == 2 && ((mB >> S.diag) & 1u)) db = stage_at(vB + __popc(mB & below));
             }
             out.x = xa + ra / da;
             out.y = xb + rb / db;
@@ -330,11 +416,13 @@ __global__ __launch_bounds__(T, 2) void spmv_vsweep_kernel(
           }
         }
         if (two) vs_st<NT>(reinterpret_cast<d2_t *>(reinterpret_cast<char *>(y) + ((unsigned)g << 3)), out);
+        else if (RPL == 1) vs_st<NT>(reinterpret_cast<double *>(reinterpret_cast<char *>(y) + ((unsigned)g << 3)), out.x);
         else *reinterpret_cast<double *>(reinterpret_cast<char *>(y) + ((unsigned)g << 3)) = out.x;
+        }
       }
       __syncthreads();   // everybody has read this plane's values
       // slab k+2 (loaded three steps ago) into the slot plane k-2 occupied; the values of plane k+1 into the stage
-      write_slab((k - k0 + 3) & (NS - 1), k + 2, st, rt, dt, xt);
+      write_slab((NS == 4) ? ((k - k0 + 3) & 3) : s3, k + 2, st, rt, dt, xt);
       write_vals(vsn);
       // look-ahead loads into the registers just consumed: ids / row pointers / aux of plane k+3, slab k+5, values k+4
       idr = load_ids(k + 3);
@@ -343,15 +431,40 @@ __global__ __launch_bounds__(T, 2) void spmv_vsweep_kernel(
       if (kExtra && extra) exr = load_pair(extra, k + 3);
       load_slab(k + 5, st, rt, dt, xt);
       vbcur = vbs;
-      vbs = vbn;
-      load_vals(vbn, vsn);
-      vbn = span_begin(k + 5);
+      if constexpr (ILV) {
+        vbn = span_begin(k + VST + 1);   // (the stage is re-loaded during the next step's products)
+      } else {
+        vbs = vbn;
+        load_vals(vbn, vsn);
+        vbn = span_begin(k + VST + 2);
+      }
       __syncthreads();
     };
+    if constexpr (VST == 2) {
+      auto &vA = vs0;
+      auto &vB = reinterpret_cast<d2u_t(&)[NVL]>(vs1);   // (NV1 == NVL here)
+      for (int k = k0; k < k1; k += 6) {   // three ring stages x two value stages
+        step(k, 0, st0, rt0, dt0, xt0, id0, rp0, ax0, ex0, vA, vb0, vB, vb1);
+        step(k + 1, 1, st1, rt1, dt1, xt1, id1, rp1, ax1, ex1, vB, vb1, vA, vb0);
+        step(k + 2, 2, st2, rt2, dt2, xt2, id2, rp2, ax2, ex2, vA, vb0, vB, vb1);
+        step(k + 3, 0, st0, rt0, dt0, xt0, id0, rp0, ax0, ex0, vB, vb1, vA, vb0);
+        step(k + 4, 1, st1, rt1, dt1, xt1, id1, rp1, ax1, ex1, vA, vb0, vB, vb1);
+        step(k + 5, 2, st2, rt2, dt2, xt2, id2, rp2, ax2, ex2, vB, vb1, vA, vb0);
+      }
+    } else {
     for (int k = k0; k < k1; k += 3) {   // straight-line body: steps at or behind k1 compute nothing (live() is false)
-      step(k, st0, rt0, dt0, xt0, id0, rp0, ax0, ex0, vs1, vb1);
-      step(k + 1, st1, rt1, dt1, xt1, id1, rp1, ax1, ex1, vs2, vb2);
-      step(k + 2, st2, rt2, dt2, xt2, id2, rp2, ax2, ex2, vs0, vb0);
+      if constexpr (VST == 3) {
+        auto &v1 = reinterpret_cast<d2u_t(&)[NVL]>(vs1);
+        auto &v2 = reinterpret_cast<d2u_t(&)[NVL]>(vs2);
+        step(k, 0, st0, rt0, dt0, xt0, id0, rp0, ax0, ex0, v1, vb1, v1, vb1);
+        step(k + 1, 1, st1, rt1, dt1, xt1, id1, rp1, ax1, ex1, v2, vb2, v2, vb2);
+        step(k + 2, 2, st2, rt2, dt2, xt2, id2, rp2, ax2, ex2, vs0, vb0, vs0, vb0);
+      } else {
+        step(k, 0, st0, rt0, dt0, xt0, id0, rp0, ax0, ex0, vs0, vb0, vs0, vb0);
+        step(k + 1, 1, st1, rt1, dt1, xt1, id1, rp1, ax1, ex1, vs0, vb0, vs0, vb0);
+        step(k + 2, 2, st2, rt2, dt2, xt2, id2, rp2, ax2, ex2, vs0, vb0, vs0, vb0);
+      }
+    }
     }
   }
   if (MODE != 0) {
@@ -394,11 +507,11 @@ struct VsCg {
   double *xupd = nullptr;
 };
 
-template <int MODE, int NL, int NVL, int T, bool PRE>
+template <int MODE, int NL, int NVL, int T, bool PRE, int RPL = 2>
 static int launch_vsweep_t(const mk_matrix *A, const SweepArgs &S, size_t lds, int blocks, bool nt, double alpha, const double *x, double beta,
                            double *y, double *slab, const int *done, const double *rhs, const double *extra, const VsCg &cg) {
   Context &c = ctx();
-  auto kern = nt ? spmv_vsweep_kernel<MODE, NL, NVL, T, true, PRE> : spmv_vsweep_kernel<MODE, NL, NVL, T, false, PRE>;
+  auto kern = nt ? spmv_vsweep_kernel<MODE, NL, NVL, T, true, PRE, RPL> : spmv_vsweep_kernel<MODE, NL, NVL, T, false, PRE, RPL>;
   // dynamic LDS above 48 KB needs an opt-in per kernel (no allocation).  The attribute belongs to the kernel, not to the
   // matrix: it is only ever raised, so a matrix with a smaller stage cannot lower it under one with a larger stage.
   static size_t lds_max[2] = {48 * 1024, 48 * 1024};   // per template instance and cache policy
@@ -418,12 +531,15 @@ static int launch_vsweep_m(const mk_matrix *A, double alpha, const double *x, do
                            int *nblocks, const double *rhs, const double *extra, const VsCg &cg = VsCg()) {
   Context &c = ctx();
   if (!A->sweep || !A->sweep_streamed || !A->pat || !A->rowpair)
-    return fail(MK_ERR_UNSUPPORTED, "spmv: MK_SPMV_VSWEEP needs rows that are sub-lists, by column offset, of one grid pattern of at most 8 entries");
+    return fail(MK_ERR_UNSUPPORTED, "spmv: MK_SPMV_VSWEEP needs rows that are sub-lists, by column offset, of one grid pattern of at most 28 entries");
   SweepArgs S = *A->sweep;
-  const int T = S.C / 2;
-  const int nvl = S.len <= 3 ? 3 : S.len <= 5 ? 5 : S.len <= 7 ? 7 : 8;
-  const size_t lds = (size_t)kNS * S.sw * 8 + ((size_t)nvl * S.C + 8) * 8 + (size_t)A->npat * 4;
-  if (S.len > 8 || lds > 160 * 1024) return fail(MK_ERR_UNSUPPORTED, "spmv: vsweep stage of %zu bytes does not fit the LDS", lds);
+  const bool long_rows = (S.rpl == 1);   // one row per lane (plan_sweep: rows of more than 8 entries)
+  const int T = long_rows ? S.C : S.C / 2;
+  const int nvl = long_rows ? (S.len <= 14 ? 7 : 14) : (S.len <= 3 ? 3 : S.len <= 5 ? 5 : S.len <= 7 ? 7 : 8);
+  const size_t lds = (size_t)(long_rows ? 3 : kNS) * S.sw * 8 + (long_rows ? (size_t)((S.len * S.C + 1) & ~1) + 8 : (size_t)nvl * S.C + 8) * 8 +
+                     (size_t)A->npat * 4;
+  if ((long_rows ? (S.len > 28 || (T != 512 && T != 256)) : S.len > 8) || lds > 160 * 1024 - 64)
+    return fail(MK_ERR_UNSUPPORTED, "spmv: vsweep stage of %zu bytes (rows of %d entries) does not fit the LDS", lds, S.len);
   const int per_cu = std::max(1, (int)((160 * 1024) / lds));
   // segments: two rounds of resident blocks (each segment re-reads two halo planes: at least 8 planes per segment)
   static const int env_nseg = getenv("MK_SWEEP_NSEG") ? atoi(getenv("MK_SWEEP_NSEG")) : 0;
@@ -439,6 +555,19 @@ static int launch_vsweep_m(const mk_matrix *A, double alpha, const double *x, do
   if (dry_launch()) return MK_OK;
   const int nl = std::max(2, (S.sw + 2 * T - 1) / (2 * T));
   const bool nt = nt_rows(A->nrows) || nt_matrix((double)A->nnz * 8.0);
+#define MK_VS1(NLL, NVV, TT) return launch_vsweep_t<MODE, NLL, NVV, TT, PRE, 1>(A, S, lds, blocks, nt, alpha, x, beta, y, slab, done, rhs, extra, cg);
+  if (long_rows) {
+    // (no CG mode for long rows: its window fill holds three streams, the register file then leaves room for ONE value stage,
+    // and the step with K3 folded in measured slower than K1 + K2 + K3 with two stages: 27-point 256^3 1.073 against 1.023 ms)
+    if constexpr (MODE == 3) return fail(MK_ERR_UNSUPPORTED, "spmv: the vsweep kernel has no fused CG mode for rows of more than 8 entries");
+    else {
+    if (T == 512 && nl == 2) { if (nvl == 7) MK_VS1(2, 7, 512) else MK_VS1(2, 14, 512) }
+    if (T == 256 && nl == 2) { if (nvl == 7) MK_VS1(2, 7, 256) else MK_VS1(2, 14, 256) }
+    if (T == 256 && nl == 3) { if (nvl == 7) MK_VS1(3, 7, 256) else MK_VS1(3, 14, 256) }
+    return fail(MK_ERR_UNSUPPORTED, "spmv: vsweep window of %d entries for chunks of %d long rows", S.sw, S.C);
+    }
+  }
+#undef MK_VS1
 #define MK_VS(NLL, NVV, TT) return launch_vsweep_t<MODE, NLL, NVV, TT, PRE>(A, S, lds, blocks, nt, alpha, x, beta, y, slab, done, rhs, extra, cg);
 #define MK_VS_NV(NLL, TT)                \
   switch (nvl) {                         \

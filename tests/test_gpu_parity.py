@@ -384,7 +384,9 @@ def _vsweep_checks(A, rp, ci, v, n, rng, jacobi=True):
 
 
 @pytest.mark.parametrize("kind,dims", [(7, (64, 64, 40)), (7, (30, 22, 10)), (5, (128, 96, 1)), (7, (512, 4, 5)), (7, (24, 16, 33)),
-                                       (7, (640, 4, 5)), (7, (1024, 3, 9)), (5, (1000, 700, 1)), (7, (6, 6, 100))])
+                                       (7, (640, 4, 5)), (7, (1024, 3, 9)), (5, (1000, 700, 1)), (7, (6, 6, 100)),
+                                       # rows of 27 entries: one row per lane, 512-row chunks
+                                       (27, (12, 12, 12)), (27, (64, 40, 20)), (27, (256, 6, 5)), (27, (500, 4, 7)), (27, (34, 30, 31)), (27, (620, 4, 5))])
 def test_spmv_vsweep_kernel_variable_coefficients(kind, dims):
     """grid operators with per-row coefficients (D A D): column offsets from the pattern table, values streamed through LDS,
     x through the window ring (vsweep.hip)"""
@@ -407,7 +409,8 @@ def test_spmv_vsweep_kernel_variable_coefficients(kind, dims):
     assert np.allclose(hist[:m], o["rel_norms"][:m], rtol=1e-8)
 
 
-@pytest.mark.parametrize("kind,dims", [(7, (64, 64, 40)), (7, (30, 22, 10)), (5, (128, 96, 1)), (7, (640, 4, 6)), (7, (1024, 3, 9)), (7, (6, 6, 100))])
+@pytest.mark.parametrize("kind,dims", [(7, (64, 64, 40)), (7, (30, 22, 10)), (5, (128, 96, 1)), (7, (640, 4, 6)), (7, (1024, 3, 9)), (7, (6, 6, 100)),
+                                       (27, (20, 18, 16)), (27, (260, 4, 6))])
 @pytest.mark.parametrize("precond", [0, 1])
 @pytest.mark.parametrize("rel_change", [0, 1])
 def test_pcg_vsweep_fused_k3_matches_oracle(kind, dims, precond, rel_change):
@@ -491,7 +494,8 @@ def test_spmv_vsweep_ragged_banded(n, hb):
     _vsweep_checks(A, rp, ci, v, n, rng)
 
 
-@pytest.mark.parametrize("seed,P,K,nbase", [(1, 640, 9, 8), (2, 1024, 5, 7), (3, 96, 40, 6), (4, 2048, 12, 5), (5, 512, 21, 3)])
+@pytest.mark.parametrize("seed,P,K,nbase", [(1, 640, 9, 8), (2, 1024, 5, 7), (3, 96, 40, 6), (4, 2048, 12, 5), (5, 512, 21, 3),
+                                            (6, 640, 9, 12), (7, 96, 40, 20), (8, 512, 21, 28), (9, 1024, 5, 9), (10, 2048, 7, 17)])
 def test_spmv_vsweep_random_patterns(seed, P, K, nbase):
     """not a grid: a random base pattern with offsets a*P + b (unsymmetric, unsorted), every row a random sub-list of it,
     every entry its own value; the kernel must reproduce the serial reference bit for bit"""
@@ -526,11 +530,11 @@ def test_spmv_vsweep_random_patterns(seed, P, K, nbase):
 
 
 def test_spmv_vsweep_eligibility():
-    rp, ci, v = oracle.stencil_csr(27, 12, 12, 12, scale_seed=2)      # 27 entries per row: the value stage does not fit
+    rp, ci, v = oracle.stencil_csr(27, 800, 4, 4, scale_seed=2)      # 27 entries per row on 800-wide planes: stage + window exceed the LDS
     n = rp.size - 1
     A = mk.Matrix.from_csr(n, n, rp, ci, v)
     assert A.info().kernel == mk.SPMV_STREAM
-    with pytest.raises(mk.MkError, match="at most 8 entries"):
+    with pytest.raises(mk.MkError, match="at most 28 entries"):
         A.set_spmv_kernel(mk.SPMV_VSWEEP)
     rp, ci, v = oracle.stencil_csr(7, 16, 16, 16)                      # constant coefficients: the table holds the values
     B = mk.Matrix.from_csr(rp.size - 1, rp.size - 1, rp, ci, v)

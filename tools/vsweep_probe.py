@@ -14,7 +14,7 @@ def time_spmv_dot(A, x, y, reps=20):
 
 dims = [tuple(int(t) for t in a.split("x")) for a in sys.argv[1:]] or [(64, 64, 40), (256, 256, 256), (512, 512, 512)]
 for (nx, ny, nz) in dims:
-    kind = 7 if nz > 1 else 5
+    kind = int(os.environ.get("MK_PROBE_KIND", "7")) if nz > 1 else 5
     A = mk.Matrix.stencil(kind, nx, ny, nz, scale_seed=1)
     n, nnz = A.nrows, A.nnz
     info = A.info()
