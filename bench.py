@@ -53,6 +53,7 @@ WORKLOADS = {
     "lap7_256_var_jacobi_pcg": (7, 256, 256, 256, 1, 1, "3D 7-pt operator 256^3 with variable coefficients, Jacobi-preconditioned CG, fp64"),
     "poisson5_1024_cg": (5, 1024, 1024, 1, 0, None, "2D 5-pt Poisson 1024^2, CG, fp64"),
     "lap27_256_cg": (27, 256, 256, 256, 0, None, "3D 27-pt stencil 256^3, CG, fp64"),
+    "lap27_256_var_cg": (27, 256, 256, 256, 0, 1, "3D 27-pt operator 256^3 with variable coefficients (BASELINE configs[3]'s stencil, one GPU's share of rows, every entry its own value), CG, fp64"),
     # BASELINE configs[3]; 3.6 G entries: row blocks only (--gpus >= 2), one matrix's int32 row pointers cannot hold it
     "lap27_512_cg": (27, 512, 512, 512, 0, None, "3D 27-pt stencil 512^3, CG, fp64, row-block partitioned"),
 }
@@ -546,6 +547,27 @@ def main():
                           "iteration_csr_model_GBps": round((12 * A2.nnz + 108 * A2.nrows) / (dt2 / args.steps) / 1e9, 1),
                           "kernel_ms": [b["avg_launch_ms"] for b in b2]}
             del A2
+        # BASELINE.json configs[3]'s stencil with real coefficients on one GPU's share of rows (2^24 rows, 449 M entries): rows of
+        # 27 entries on the vsweep kernel's one-row-per-lane form; product + dots timed alone, then the CG loop (K1 + K2 + K3)
+        try:
+            sname = "lap27_256_var_cg"
+            A2, dt2, res2, kt2 = measure(sname, args.steps, args.warmup)
+            x2, y2 = mk.Vector(A2.nrows, fill=1.0), mk.Vector(A2.nrows)
+            for _ in range(3):
+                A2.spmv_dot(x2, y2, want=False)
+            mk.timer_start()
+            for _ in range(20):
+                A2.spmv_dot(x2, y2, want=False)
+            ms2 = mk.timer_stop() / 20
+            sb2 = 12 * A2.nnz + 20 * A2.nrows + 4
+            sec[sname] = {"workload": WORKLOADS[sname][6], "value": round(args.steps / dt2, 2), "unit": "CG iterations/s",
+                          "ms_per_step": round(dt2 * 1e3 / args.steps, 4), "spmv_kernel": KERNEL_NAMES.get(A2.info().kernel),
+                          "iteration_frac": round((12 * A2.nnz + 92 * A2.nrows) / (dt2 / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+                          "spmv_dot_ms": round(ms2, 4), "spmv_frac": round(sb2 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                          "spmv_bytes_model": "SURVEY 8(d): 12 nnz + 20 n + 4", "kernel_ms": [round(k[0], 4) for k in kt2]}
+            del A2, x2, y2
+        except Exception as e:      # never lose the headline to a secondary measurement
+            sec["lap27_256_var_cg"] = {"error": repr(e)}
         # BASELINE.json configs[2]: R-MAT scale 24, 2^28 edges: COO -> CSR on the device, then SpMV (split kernel)
         try:
             scale, ne = 24, 1 << 28

@@ -400,7 +400,9 @@ static int plan_sweep(mk_matrix *A, const std::vector<int> &tab, const std::vect
   A->sweep_auto = (int64_t)S.ncp * std::max(1, S.K / 8) >= (env_min > 0 ? (int64_t)env_min : 2 * (int64_t)ctx().num_cus);
   // long rows on the vsweep kernel: one block per CU, so the grid must be large for its prologues to vanish (27-point 128^3:
   // 0.136 ms against 0.115 ms on the stream kernel; 256^3: 0.815 against 0.896 ms)
-  if (S.rpl == 1 && env_min <= 0 && A->nrows < 6 * 1000 * 1000) A->sweep_auto = false;
+  // ... and the rows long: 2-D 9-point 3000^2 with its own values runs at 0.61 of the roofline here, 0.87 on the stream kernel with
+  // its index patterns (its 72 B of values per row do not pay for a block-wide barrier pair per 512 rows)
+  if (S.rpl == 1 && env_min <= 0 && (A->nrows < 6 * 1000 * 1000 || len < 20)) A->sweep_auto = false;
   return MK_OK;
 }
 

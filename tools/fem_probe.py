@@ -92,7 +92,7 @@ def run(name, n, rp, ci):
     mk.synchronize(); t_an = (time.perf_counter() - t0) * 1e3
     x, y = mk.Vector(n, fill=1.0), mk.Vector(n)
     b = 12 * nnz + 20 * n + 4
-    out = [f"{name}: rows {n} mean {nnz / n:.1f} max {i.max_row_len} default {i.kernel} patterns {i.index_patterns} lanes {i.stream_lanes} chunk {i.stream_chunk} shared {i.shared_columns / max(nnz, 1):.2f} analysis {t_an:.2f} ms |"]
+    out = [f"{name}: rows {n} mean {nnz / n:.1f} max {i.max_row_len} default {i.kernel} patterns {i.index_patterns} lanes {i.stream_lanes} chunk {i.stream_chunk} shared {i.shared_columns / max(nnz, 1):.2f} groups {i.row_groups} glanes {i.group_lanes} analysis {t_an:.2f} ms |"]
     for k in (0, 1, 2, 3):
         try:
             A.set_spmv_kernel(k)

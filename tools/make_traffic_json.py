@@ -67,7 +67,11 @@ for what, pat, keep, dest, note in (
          f"profiles/{TAG}_pmc_convert_rmat.json", "tools/rmat_probe.py: R-MAT scale 24, 2^28 entries: COO->CSR on the device, then SpMV (split kernel)"),
         ("group", f"gpurun_out/{TAG}_pmc_group_*", ("spmv_group", "spmv_stream"),
          f"profiles/{TAG}_pmc_row_group.json", "tools/group_probe.py 500000 26 300: FE-like matrix (3 unknowns per node, random neighbour nodes; "
-                                              "bench.py's secondary.fem_rand3_500k) through the row-group kernel")):
+                                              "bench.py's secondary.fem_rand3_500k) through the row-group kernel"),
+        ("vsweep27", f"gpurun_out/{TAG}_pmc_vsweep27_*", ("spmv_vsweep", "spmv_stream"),
+         f"profiles/{TAG}_pmc_vsweep_27pt.json", "MK_PROBE_KIND=27 tools/vsweep_probe.py 256x256x256: 27-point operator with variable coefficients "
+                                                "(2^24 rows, 449 M entries) through the long-row form of the vsweep kernel (one row per lane) and, for "
+                                                "comparison, the stream kernel; algorithmic bytes 12 nnz + 20 n + 4 = 5.72 GB, the vsweep kernel moves 8 nnz + 22 n + 4 n")):
     agg = passes(pat + "/**/pmc_counter_collection.csv") or passes(pat + "/pmc_counter_collection.csv")
     o = {"what": "rocprofv3 --pmc, one pass per counter group, on " + note + "; HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024", "kernels": {}}
     for k, d in sorted(agg.items()):
