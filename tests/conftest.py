@@ -16,7 +16,8 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 GOLDEN_CASES = ["poisson5_6x5_sorted", "poisson5_6x5_shuffled", "ragged_dups_empty_rows",
                 "symmetric_lower", "pattern_general", "pattern_symmetric", "skewed_one_long_row",
-                "empty_matrix", "one_by_one", "random_70k"]
+                "empty_matrix", "one_by_one", "random_70k",
+                "array_sorting_kat"]      # the sort-by-key input of test/array_sorting.cpp:35-36, sorted by the reference itself
 
 
 @pytest.fixture(scope="session")
