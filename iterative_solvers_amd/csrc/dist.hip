@@ -1041,7 +1041,7 @@ int mk_dist_pcg_solve(int R, mk_pcg **solvers, mk_dist_matrix **A, mk_vector **b
   bool single = false;
   if (want_single) {
     double bad = 0.0;
-    for (int r = 0; r < R; r++) if (!pfuse[r]) bad += 1.0;
+    for (int r = 0; r < R; r++) if (!pfuse[r] || !sweep_single_ok(&A[r]->diag)) bad += 1.0;
     if (A[0]->comm != nullptr && !A[0]->comm->local) {
       MK_DH(hipMemcpyAsync(W[0].buf, &bad, sizeof(double), hipMemcpyHostToDevice, c.stream));
       MK_D(dist_all_reduce(R, A, bufs.data(), 1));

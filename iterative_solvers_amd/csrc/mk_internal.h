@@ -238,6 +238,7 @@ int launch_sweep_cg_pdots(const mk_matrix *A, const double *r, const double *p_o
 int sweep_uniform_diag(const mk_matrix *A, double *inv_diag);
 //   single : the single-reduction step (opt-in): both halves of the step in one sweep behind ONE reduction of five values
 //            (<A r, r>, <r,z>, <r,r>, <x,x>, <p,p>); see spmv_sweep_kernel MODE 6.  r and p are ping-ponged by the caller.
+int sweep_single_ok(const mk_matrix *A);   // MODE 6 is available for this matrix's sweep plan
 int launch_sweep_cg_single(const mk_matrix *A, const double *r_old, double *r_new, const double *p_old, double *p_new, double *x,
                            double zscale, const double *extra, int gap0, int gap1, const double *sr_in, double *slab_out,
                            PcgState *st, int two_norm, int rel_change, int first, int parity, double *norms, int *nblocks);

@@ -2256,10 +2256,14 @@ int launch_sweep_cg_single(const mk_matrix *A, const double *r_old, double *r_ne
                            double zscale, const double *extra, int gap0, int gap1, const double *sr_in, double *slab_out,
                            PcgState *st, int two_norm, int rel_change, int first, int parity, double *norms, int *nblocks) {
   if (r_old == r_new || p_old == p_new) return fail(MK_ERR_INVALID, "single-reduction CG step: r and p are read through other blocks' windows and cannot be updated in place");
+  if (!sweep_single_ok(A)) return fail(MK_ERR_UNSUPPORTED, "single-reduction CG step: not with 2048-row chunks (register budget)");
   return launch_sweep<6>(A, zscale, p_old, 0.0, p_new, slab_out, nullptr, nblocks, r_old, extra, st, sr_in, 1, 1, x,
                          (two_norm ? 1 : 0) | (rel_change ? 2 : 0) | (first ? 4 : 0) | ((parity & 1) << 3), norms, 0, 0, kSlabStride, r_new,
                          (gap0 + 1) & ~1, gap1);
 }
+
+// the single-reduction step's kernel (MODE 6) needs ~157 VGPRs: chunks of 2048 rows (1024 threads, 128 VGPRs each) would spill
+int sweep_single_ok(const mk_matrix *A) { return A->sweep && !A->sweep_streamed && A->sweep->C <= 1024; }
 
 int sweep_uniform_diag(const mk_matrix *A, double *inv_diag) {
   if (!A->sweep || !A->sweep_diag_uniform || A->sweep_streamed) return 0;

@@ -252,6 +252,25 @@ def test_dist_pcg_single_reduction_falls_back():
     res = mkd.dist_pcg_solve(Ss, As, bs, xs)
     assert not any(S.single_reduction_used() for S in Ss)
     assert res[0]["converged"] == 1 and abs(res[0]["iterations"] - o["iterations"]) <= 2
+    # constant coefficients on planes so wide that the sweep plan takes 2048-row chunks (1024 threads: the single-reduction
+    # kernel would not fit the register budget): declined as well
+    dims = (700, 4, 12)
+    rp, ci, v = oracle.stencil_csr(7, *dims)
+    n = rp.size - 1
+    bh = np.random.default_rng(4).normal(size=n)
+    o = oracle.pcg(rp, ci, v, bh, tol=1e-9, precond=0, maxit=2000)
+    rs = mkd.slab_row_start(*dims, 2)
+    As = _blocks(rp, ci, v, n, rs, mkd.Comm.local_world(2))
+    for A in As:
+        A.set_spmv_kernel(mk.SPMV_SWEEP)
+    bs = [A.vector(values=bh[rs[k]:rs[k + 1]]) for k, A in enumerate(As)]
+    xs = [A.vector(fill=0.0) for A in As]
+    Ss = [mk.PCG(max_iter=2000, tol=1e-9) for _ in As]
+    for S in Ss:
+        S.set_single_reduction(True)
+    res = mkd.dist_pcg_solve(Ss, As, bs, xs)
+    assert not any(S.single_reduction_used() for S in Ss)
+    assert res[0]["converged"] == 1 and abs(res[0]["iterations"] - o["iterations"]) <= 2
 
 
 @pytest.mark.parametrize("world,precond,sweep", [(2, 0, False), (2, 1, True), (4, 0, True), (4, 1, False), (8, 0, True), (8, 1, True)])
