@@ -425,7 +425,10 @@ def main():
         if fused:
             # fused step on sweep matrices: first sweep p' = z + beta p and the dots of A p' (2 + 8 + 8 + 8 B/row),
             # second sweep r -= alpha A p' recomputed, x += alpha p' (2 + 8 + 16 + 16 B/row); K3 rides in the first
+            halfx = not os.environ.get("MK_NO_HALVED_X") and not (kt is not None and len(kt) == 3)   # 
             slots = [("spmv_sweep_kernel MODE 5 (p' = z + beta p in the window fill, dots of A p')", 26 * n, "26 B/row: 2 B pattern id, r 8, p 8, p' 8"),
+                     ("spmv_sweep_kernel MODE 7 / 8 alternating (r -= alpha A p recomputed, dots; the solution update x += alpha_prev p_prev + alpha p every second step)",
+                      34 * n, "34 B/row on average: 2 B pattern id, p 8, r 8 + 8, and x 8 + 8 in every second step (26 B and 42 B)") if halfx else
                      ("spmv_sweep_kernel MODE 4 (r -= alpha A p recomputed, x += alpha p, dots)", 42 * n, "42 B/row: 2 B pattern id, p 8, r 8 + 8, x 8 + 8")]
             if kt is not None and len(kt) == 3:
                 slots.append(("pcg_update_p_kernel (K3)", 24 * n, "24 B/row"))

@@ -595,9 +595,10 @@ static __global__ void single_offd_kernel(int nrows, const int *__restrict__ row
 static __global__ void single_final_test_kernel(const double *__restrict__ buf, PcgState *st, int flags, double *__restrict__ norms, int parity) {
   if (threadIdx.x != 0 || blockIdx.x != 0 || st->done != 0) return;
   const double gamma_new = buf[1], i_prod = (flags & 1) ? buf[2] : buf[1], al = st->sr_alpha[parity ^ 1];
+  const double xx = (buf[3] != 0.0) ? buf[3] : st->xx_last;   // (a last step that left x alone handed on zeros)
   bool conv = (i_prod / st->bi_prod < st->eps);
   if (conv && (flags & 2) && i_prod > 0.0) {
-    const double ratio = al * al * buf[4] / buf[3];
+    const double ratio = al * al * buf[4] / xx;
     if (ratio >= st->eps) conv = false;
   }
   st->gamma = gamma_new;
@@ -1099,6 +1100,10 @@ int mk_dist_pcg_solve(int R, mk_pcg **solvers, mk_dist_matrix **A, mk_vector **b
     std::vector<double *> rcur(R), rnew(R), pnew(R);
     std::vector<int> nbk2(R, 0);
     const int tflags = (two_norm ? 1 : 0) | (rel_change ? 2 : 0);
+    // the solution update every second step with both steps' terms (sweep MODE 9 / 10, as MODE 7 / 8 of the single-matrix solve):
+    // 52 B per row and iteration on average
+    static const int no_halfx = getenv("MK_NO_HALVED_X") ? atoi(getenv("MK_NO_HALVED_X")) : 0;
+    const bool halfx = !no_halfx && S0->max_iter > 1;
     for (int r = 0; r < R; r++) { rcur[r] = W[r].r; rnew[r] = W[r].s; pv[r] = W[r].p; pnew[r] = W[r].p2; }
     int it = 0;
     for (; it < S0->max_iter && !stop; it++) {
@@ -1118,7 +1123,8 @@ int mk_dist_pcg_solve(int R, mk_pcg **solvers, mk_dist_matrix **A, mk_vector **b
           hipLaunchKernelGGL(single_offd_kernel, dim3(grid1(A[r]->n_offd_rows, 1024)), dim3(256), 0, c.stream, A[r]->n_offd_rows, A[r]->offd_rows,
                              W[r].t, W[r].tpf, W[r].buf, W[r].state, zs[r], first, par);
         MK_D(launch_sweep_cg_single(&A[r]->diag, rcur[r], rnew[r], pv[r], pnew[r], x[r]->d, zs[r], W[r].tpf, W[r].tpf ? A[r]->gap0 : 0,
-                                    W[r].tpf ? A[r]->gap1 : 0, W[r].buf, W[r].slab2, W[r].state, two_norm, rel_change, first, par, W[r].norms, &nbk2[r]));
+                                    W[r].tpf ? A[r]->gap1 : 0, W[r].buf, W[r].slab2, W[r].state, two_norm, rel_change, first, par, W[r].norms, &nbk2[r],
+                                    halfx ? 1 + (it & 1) : 0, pnew[r] == W[r].p2 ? 1 : 0));
         std::swap(rcur[r], rnew[r]);
         std::swap(pv[r], pnew[r]);
       }
@@ -1128,6 +1134,11 @@ int mk_dist_pcg_solve(int R, mk_pcg **solvers, mk_dist_matrix **A, mk_vector **b
         if (hst[0].done != 0) stop = true;
       }
     }
+    if (halfx && it > 0)         // a solve that ended on a step that left x alone: its update is still pending
+      for (int r = 0; r < R; r++) {
+        hipLaunchKernelGGL(pcg_apply_pending_x_kernel, dim3(vb[r]), dim3(kVecThreads), 0, c.stream, A[r]->n_local, x[r]->d, W[r].p, W[r].p2, W[r].state);
+        hipLaunchKernelGGL(pcg_clear_pending_kernel, dim3(1), dim3(1), 0, c.stream, W[r].state);
+      }
     if (it > 0 && !zero_rhs) {   // the test of the last step (one more reduction, once per solve)
       for (int r = 0; r < R; r++)
         hipLaunchKernelGGL(single_fold_kernel, dim3(1), dim3(kVecThreads), 0, c.stream, W[r].slab1, 0, W[r].slab2, nbk2[r], W[r].buf);

@@ -162,6 +162,10 @@ int mk_pcg_solve(mk_pcg *S, const mk_matrix *A, const mk_vector *b, mk_vector *x
   // (not with the Jacobi preconditioner: its 1/diag is a third window stream already and the kernel runs out of registers:
   // 256^3 0.511 -> 0.535 ms per iteration; without a preconditioner 512^3 3.58 -> 3.32 ms, 256^3 0.436 -> 0.434)
   const bool defx = vfuse && !no_defx && !dinv;
+  // Constant-coefficient sweeps: the solution update is 16 of the step's 68 B per row; x is updated every SECOND step with
+  // both steps' terms (sweep MODE 7 / 8): 60 B per row on average.  MK_NO_HALVED_X=1 keeps x += alpha p in every step.
+  static const int no_halfx = getenv("MK_NO_HALVED_X") ? atoi(getenv("MK_NO_HALVED_X")) : 0;
+  const bool halfx = fuse_p && !no_halfx && S->max_iter > 1;
   int nb2 = 0;
   // kernel timing: an event in front of every kernel of iterations 1 .. kTimedIters (the first iteration runs another
   // first kernel on the fused path) and one behind the last of them
@@ -186,7 +190,8 @@ int mk_pcg_solve(mk_pcg *S, const mk_matrix *A, const mk_vector *b, mk_vector *x
         MK_TRY(launch_sweep_cg_dots(A, pcur, S->slab1, S->state, &nb1));
       }
       stamp(it);
-      MK_TRY(launch_sweep_cg_resid_x(A, pcur, S->r, x->d, dinv, S->slab1, nb1, kSlabStride, S->slab2, S->state, &nb2));
+      MK_TRY(launch_sweep_cg_resid_x(A, pcur, S->r, x->d, dinv, S->slab1, nb1, kSlabStride, S->slab2, S->state, &nb2,
+                                     halfx ? 1 + (it & 1) : 0, it & 1, pcur == S->s ? 1 : 0));
       if (!fuse_p) {
         stamp(it);
         if (dinv)
@@ -245,6 +250,10 @@ int mk_pcg_solve(mk_pcg *S, const mk_matrix *A, const mk_vector *b, mk_vector *x
   if (tev_used > 0 && tev_used == timed_iters * nslots) (void)hipEventRecord(S->tev[tev_used++], c.stream);   // solve ended with the timed window
   if (defx && S->max_iter > 1) {   // the solution update of the last completed step, if it is still pending
     hipLaunchKernelGGL(pcg_apply_pending_x_kernel, dim3(vb), dim3(kVecThreads), 0, c.stream, n, x->d, S->p, S->p2, S->state);
+    hipLaunchKernelGGL(pcg_clear_pending_kernel, dim3(1), dim3(1), 0, c.stream, S->state);
+  }
+  if (halfx) {                     // ... likewise after a solve that ended on an even step of the halved update (p buffers: S->p, S->s)
+    hipLaunchKernelGGL(pcg_apply_pending_x_kernel, dim3(vb), dim3(kVecThreads), 0, c.stream, n, x->d, S->p, S->s, S->state);
     hipLaunchKernelGGL(pcg_clear_pending_kernel, dim3(1), dim3(1), 0, c.stream, S->state);
   }
   if ((fuse_p || vfuse) && S->max_iter > 0)   // the test that the next step's first kernel would have made (K3's prologue; n = 0: no p update)

@@ -112,6 +112,7 @@ struct PcgState {
   int pbuf;        // ... and which of the two p buffers that p is in
   int pad;
   double sr_alpha[2], sr_gamma[2];   // single-reduction step: alpha and gamma of the last two steps by parity (read [parity ^ 1], write [parity])
+  double beta_last, xx_last;         // halved solution update (sweep MODE 7 / 8): beta and <x,x> of the step's K3
 };
 
 // grid-level reduction slabs: component k of block b lives at slab[k * stride + b]
@@ -180,7 +181,7 @@ struct mk_matrix {
   int *rowpair = nullptr;          // vsweep kernel: rowptr[0], rowptr[2], ... (first value of every lane's row pair)
   bool sweep_streamed = false;     // the plan matches column offsets only: values are streamed from val[] (spmv_vsweep_kernel)
   unsigned short *sweep_perm = nullptr;   // sweep kernel, rows of more than 8 entries: row pair each lane of a chunk owns (ncp x C/2)
-  mutable int sweep_bpc[7] = {0, 0, 0, 0, 0, 0, 0};
+  mutable int sweep_bpc[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   bool sweep_diag_uniform = false; // every row has the (single) diagonal entry of the base pattern
   int npat = 0, pml = 0;
   int max_off = 0;                 // largest |column - row| over all patterns
@@ -241,9 +242,14 @@ int sweep_uniform_diag(const mk_matrix *A, double *inv_diag);
 int sweep_single_ok(const mk_matrix *A);   // MODE 6 is available for this matrix's sweep plan
 int launch_sweep_cg_single(const mk_matrix *A, const double *r_old, double *r_new, const double *p_old, double *p_new, double *x,
                            double zscale, const double *extra, int gap0, int gap1, const double *sr_in, double *slab_out,
-                           PcgState *st, int two_norm, int rel_change, int first, int parity, double *norms, int *nblocks);
+                           PcgState *st, int two_norm, int rel_change, int first, int parity, double *norms, int *nblocks, int xmode = 0,
+                           int pbuf = 0);
+//            xmode 0: x += alpha p every step.  1 / 2 (alternating, from step 0 on): the halved solution update -- step 2k leaves
+//            x alone (pending in the state record), step 2k + 1 adds both steps' updates (see spmv_sweep_kernel MODE 7 / 8);
+//            parity = step & 1, pbuf = which of the caller's two p buffers `p` is (for pcg_apply_pending_x_kernel)
 int launch_sweep_cg_resid_x(const mk_matrix *A, const double *p, double *r, double *x, const double *dinv, const double *slab_in,
-                            int nblocks_in, int stride_in, double *slab_out, PcgState *st, int *nblocks);
+                            int nblocks_in, int stride_in, double *slab_out, PcgState *st, int *nblocks, int xmode = 0, int parity = 0,
+                            int pbuf = 0);
 
 // sweep over grid matrices with per-row values (vsweep.hip); mode 0: y = alpha A x + beta y, 1: y = A x + partials of
 // <y,x>, <x,x>, 2: Jacobi sweep (as launch_jacobi_sweep)

@@ -1365,6 +1365,12 @@ __global__ __launch_bounds__(T, T == 512 ? 2 : 1) void spmv_sweep_kernel(
   //         convergence test, beta from slab_in); the window is filled with p' = z + beta x (z = alpha * rhs, alpha = 1
   //         or the uniform 1/diag) instead of x, the block's own rows of p' go to y, then as MODE 3 on p'.
   //         flags: bit 0 two_norm, bit 1 rel_change.
+  // MODE 7, 8 (MODE 4 with the solution update halved): x += alpha p is 16 of the step's 68 B per row.  Even steps (MODE 7) leave
+  //         x alone (the update stays pending: state record x_pending / pbuf, applied after the loop if the solve ends there);
+  //         odd steps (MODE 8) add both, x += alpha_prev p_prev + alpha p, with p_prev = (p - z) / beta rebuilt from what the sweep
+  //         holds anyway (p in the window, r before its update, beta of this step's K3): same sum, x rounded once instead of
+  //         twice.  <x,x> of a MODE 7 step is the last one known (rel_change looks at it only once the residual test has passed).
+  //         flags: bit 3 parity of the step (alpha by parity, as in MODE 6), bit 6 which p buffer x is the window of.
   // MODE 6 (single-reduction CG step, opt-in): MODE 5's window fill and MODE 4's body in ONE kernel behind ONE reduction.
   //         slab_in: <A r, r>, <r,z>, <r,r>, <x,x>, <p,p> (all-reduced).  Prologue: the convergence test of the step before
   //         (K3's), beta = gamma' / gamma, then alpha = gamma' / (zscale^2 <A r, r> - beta gamma' / alpha_old) -- the
@@ -1382,13 +1388,19 @@ __global__ __launch_bounds__(T, T == 512 ? 2 : 1) void spmv_sweep_kernel(
   unsigned *smask = reinterpret_cast<unsigned *>(ring + NS * sw);   // npat
   const int tid = threadIdx.x;
   double acg = 0.0;   // MODE 6: the step's alpha (`alpha` keeps zscale for the window fill)
+  constexpr bool kM4 = (MODE == 4 || MODE == 7 || MODE == 8);
+  constexpr bool kM6 = (MODE == 6 || MODE == 9 || MODE == 10);   // 9 / 10: MODE 6 with the halved solution update (as 7 / 8)
+  double al_prev = 0.0, inv_beta = 0.0, xx_last = 0.0;   // MODE 7 / 8
   if (MODE >= 3) {
     if (block_flag_raised(&st->done)) return;
-    if (MODE == 4) {   // K2's prologue
+    if (kM4) {   // K2's prologue
       const bool leader = (blockIdx.x == 0 && tid == 0);
       double d[2];
       reduce_slab<2, T>(slab_in, nblocks_in, stride_in, d, ring);
       const double sdotp = d[0], gamma = st->gamma;
+      const int par4 = (flags >> 3) & 1;
+      if (MODE == 8) { al_prev = st->sr_alpha[par4 ^ 1]; inv_beta = 1.0 / st->beta_last; }
+      if (MODE == 7) xx_last = st->xx_last;
       __syncthreads();
       if (sdotp == 0.0) {
         if (leader) { st->iter += 1; st->breakdown = 1; st->done = 2; }
@@ -1399,7 +1411,11 @@ __global__ __launch_bounds__(T, T == 512 ? 2 : 1) void spmv_sweep_kernel(
         if (leader) { st->iter += 1; st->breakdown = 2; st->done = 2; }
         return;
       }
-      if (leader) { st->alpha = alpha; st->gamma_old = gamma; st->pp = d[1]; st->sdotp = sdotp; st->iter += 1; }
+      if (leader) {
+        st->alpha = alpha; st->gamma_old = gamma; st->pp = d[1]; st->sdotp = sdotp; st->iter += 1;
+        if (MODE == 7) { st->sr_alpha[par4] = alpha; st->x_pending = 1; st->pbuf = (flags >> 6) & 1; }
+        if (MODE == 8) { st->sr_alpha[par4] = alpha; st->x_pending = 0; }
+      }
     }
     if (MODE == 5) {   // K3's prologue
       const bool leader = (blockIdx.x == 0 && tid == 0);
@@ -1422,11 +1438,13 @@ __global__ __launch_bounds__(T, T == 512 ? 2 : 1) void spmv_sweep_kernel(
         if (norms) norms[st->iter] = sqrt(i_prod / bi_prod);
         if (conv) { st->converged = 1; st->done = 1; }
         else if (tiny_gamma) { st->breakdown = 3; st->done = 2; }
+        st->xx_last = xx;                          // (MODE 7 / 8 of this step read them: a later launch)
+        st->beta_last = gamma_new / gamma_old;
       }
       if (conv || tiny_gamma) return;
       beta = gamma_new / gamma_old;
     }
-    if (MODE == 6) {
+    if (kM6) {
       const bool leader = (blockIdx.x == 0 && tid == 0);
       double d[5];
       reduce_slab<5, T>(slab_in, nblocks_in, stride_in, d, ring);
@@ -1435,11 +1453,13 @@ __global__ __launch_bounds__(T, T == 512 ? 2 : 1) void spmv_sweep_kernel(
       const double bi_prod = st->bi_prod, eps = st->eps, al_old = st->sr_alpha[par ^ 1], gamma_old = st->sr_gamma[par ^ 1];
       const double gamma_new = first ? st->gamma : d[1];
       __syncthreads();
+      // <x,x>: steps that left x alone (MODE 9) hand on zeros; the last value known stands in (every rank holds the same)
+      const double xx6 = (d[3] != 0.0) ? d[3] : st->xx_last;
       if (!first) {
         const double i_prod = (flags & 1) ? d[2] : d[1];
         bool conv = (i_prod / bi_prod < eps);
         if (conv && (flags & 2) && i_prod > 0.0) {
-          const double ratio = al_old * al_old * d[4] / d[3];
+          const double ratio = al_old * al_old * d[4] / xx6;
           if (ratio >= eps) conv = false;
         }
         const bool tiny_gamma = (gamma_new < DBL_MIN) && (-gamma_new < DBL_MIN);
@@ -1455,6 +1475,7 @@ __global__ __launch_bounds__(T, T == 512 ? 2 : 1) void spmv_sweep_kernel(
       } else {
         beta = 0.0;
       }
+      if (MODE == 10) { al_prev = al_old; inv_beta = 1.0 / beta; }
       const double azz = (alpha * alpha) * d[0];                                   // <A z, z>, z = zscale r
       const double sdotp = first ? azz : azz - beta * gamma_new / al_old;          // = <A p', p'>
       if (sdotp == 0.0) {
@@ -1469,6 +1490,9 @@ __global__ __launch_bounds__(T, T == 512 ? 2 : 1) void spmv_sweep_kernel(
       if (leader) {
         st->alpha = acg; st->gamma_old = gamma_new; st->sdotp = sdotp; st->iter += 1;
         st->sr_alpha[par] = acg; st->sr_gamma[par] = gamma_new;
+        st->xx_last = xx6;
+        if (MODE == 9) { st->x_pending = 1; st->pbuf = (flags >> 6) & 1; }
+        if (MODE == 10) st->x_pending = 0;
       }
     }
     __syncthreads();   // ring was reduction scratch
@@ -1497,7 +1521,7 @@ __global__ __launch_bounds__(T, T == 512 ? 2 : 1) void spmv_sweep_kernel(
     // row refers to (their mask bit is clear) or are never read.
     const int xlast = ((int)ncols - 1) & ~1;   // x[xlast], x[xlast+1]: inside the allocation (slack behind ncols)
     const int rlast = (nr - 1) & ~1;
-    constexpr bool kFill = (MODE == 5 || MODE == 6);   // the window is p' = z + beta p, formed while it is filled
+    constexpr bool kFill = (MODE == 5 || kM6);   // the window is p' = z + beta p, formed while it is filled
     constexpr int NLR = kFill ? NL : 1;   // second window stream (the residual) only then
     auto load_slab = [&](int j, d2_t(&reg)[NL], d2_t(&regr)[NLR]) {   // window of plane j
       const int g0 = min(j, k1) * S.P + r0 - S.wlo + lw;
@@ -1548,17 +1572,17 @@ __global__ __launch_bounds__(T, T == 512 ? 2 : 1) void spmv_sweep_kernel(
       const int g = min(row_of(j), rlast);
       return MK_SWEEP_LD(reinterpret_cast<const d2_t *>(reinterpret_cast<const char *>(p) + ((unsigned)g << 3)));
     };
-    const double *aux = (MODE == 2 || MODE == 4 || MODE == 6) ? rhs : (MODE == 0 && beta != 0.0) ? y : nullptr;
-    constexpr bool kExtra = (MODE == 2 || MODE == 4 || MODE == 6);
-    constexpr bool kXupd = (MODE == 4 || MODE == 6);
+    const double *aux = (MODE == 2 || kM4 || kM6) ? rhs : (MODE == 0 && beta != 0.0) ? y : nullptr;
+    constexpr bool kExtra = (MODE == 2 || kM4 || kM6);
+    constexpr bool kXupd = (MODE == 4 || MODE == 8 || MODE == 6 || MODE == 10);
     // MODE 2, row-block Jacobi: `extra` (the off-rank product) is zero on every row that touches no ghost.  The caller names
     // the largest run of such rows [gap0, gap1) (in nblocks_in / stride_in, which this mode has no other use for): lanes
     // inside it all read the pair at gap0 -- the load stays unconditional, HBM sees one line instead of 8 B per row.
     // (MODE 6: the same for the off-rank part of A p', run named in S.gap0 / S.gap1)
-    const int gap0 = (MODE == 2) ? nblocks_in : (MODE == 6) ? S.gap0 : 0, gap1 = (MODE == 2) ? stride_in : (MODE == 6) ? S.gap1 : 0;
+    const int gap0 = (MODE == 2) ? nblocks_in : kM6 ? S.gap0 : 0, gap1 = (MODE == 2) ? stride_in : kM6 ? S.gap1 : 0;
     auto load_extra = [&](int j) -> d2_t {
       int g = min(row_of(j), rlast);
-      if (MODE == 2 || MODE == 6) g = (g >= gap0 && g + 1 < gap1) ? gap0 : g;
+      if (MODE == 2 || kM6) g = (g >= gap0 && g + 1 < gap1) ? gap0 : g;
       return MK_SWEEP_LD(reinterpret_cast<const d2_t *>(reinterpret_cast<const char *>(extra) + ((unsigned)g << 3)));
     };
 
@@ -1716,9 +1740,14 @@ __global__ __launch_bounds__(T, T == 512 ? 2 : 1) void spmv_sweep_kernel(
             out.y = xb + rb / db;
             acc0 += ra * ra;
             if (two) acc0 += rb * rb;
-          } else if (MODE == 4) {
-            {
+          } else if (kM4) {
+            if (MODE != 7) {
               d2_t xv = xu0;
+              if (MODE == 8) {   // the pending update of the step before: p_prev = (p - z) / beta, z = r (scaled) before this step's update
+                const double zpa = (beta != 0.0) ? ax0.x * beta : ax0.x, zpb = (beta != 0.0) ? ax0.y * beta : ax0.y;
+                xv.x += al_prev * ((xa - zpa) * inv_beta);
+                xv.y += al_prev * ((xb - zpb) * inv_beta);
+              }
               xv.x += alpha * xa;
               xv.y += alpha * xb;
               acc2 += xv.x * xv.x;
@@ -1739,16 +1768,20 @@ __global__ __launch_bounds__(T, T == 512 ? 2 : 1) void spmv_sweep_kernel(
             acc0 += ra * za;
             acc1 += ra * ra;
             if (two) { acc0 += rb * zb; acc1 += rb * rb; }
-          } else if (MODE == 6) {
-            {
+          } else if (kM6) {
+            acc3 += xa * xa;
+            if (two) acc3 += xb * xb;
+            if (MODE != 9) {
               d2_t xv = xu0;
+              if (MODE == 10) {   // the pending update of the step before: p_prev = (p' - z) / beta, z = zscale r before this step's update
+                xv.x += al_prev * ((xa - ax0.x * alpha) * inv_beta);
+                xv.y += al_prev * ((xb - ax0.y * alpha) * inv_beta);
+              }
               xv.x += acg * xa;
               xv.y += acg * xb;
               acc2 += xv.x * xv.x;
-              acc3 += xa * xa;
               if (two) {
                 acc2 += xv.y * xv.y;
-                acc3 += xb * xb;
                 MK_SWEEP_ST(reinterpret_cast<d2_t *>(reinterpret_cast<char *>(xupd) + ((unsigned)g << 3)), xv);
               } else {
                 *reinterpret_cast<double *>(reinterpret_cast<char *>(xupd) + ((unsigned)g << 3)) = xv.x;
@@ -1773,7 +1806,7 @@ __global__ __launch_bounds__(T, T == 512 ? 2 : 1) void spmv_sweep_kernel(
           }
         }
         if (MODE != 3 && MODE != 5) {
-          double *dst = (MODE == 6) ? y2 : y;   // (MODE 6: y holds the new p, written by the window fill)
+          double *dst = kM6 ? y2 : y;   // (MODE 6: y holds the new p, written by the window fill)
           if (two) MK_SWEEP_ST(reinterpret_cast<d2_t *>(reinterpret_cast<char *>(dst) + ((unsigned)g << 3)), out);
           else *reinterpret_cast<double *>(reinterpret_cast<char *>(dst) + ((unsigned)g << 3)) = out.x;
         }
@@ -1796,16 +1829,17 @@ __global__ __launch_bounds__(T, T == 512 ? 2 : 1) void spmv_sweep_kernel(
   }
   if (MODE != 0) {
     __syncthreads();
-    constexpr int NACC = (MODE == 6) ? 4 : 3;
+    constexpr int NACC = kM6 ? 4 : 3;
     double w[NACC];
     w[0] = acc0; w[1] = acc1; w[2] = acc2;
-    if (MODE == 6) w[NACC - 1] = acc3;
+    if (kM6) w[NACC - 1] = acc3;
     block_sum<NACC, T>(w, ring);
+    if (MODE == 7) w[2] = (blockIdx.x == 0) ? xx_last : 0.0;   // <x,x> as last known
     if (threadIdx.x == 0) {
       slab[0 * kSlabStride + blockIdx.x] = w[0];
       if (MODE != 2) slab[1 * kSlabStride + blockIdx.x] = w[1];
-      if (MODE == 4 || MODE == 6) slab[2 * kSlabStride + blockIdx.x] = w[2];
-      if (MODE == 6) slab[3 * kSlabStride + blockIdx.x] = w[NACC - 1];
+      if (kM4 || kM6) slab[2 * kSlabStride + blockIdx.x] = w[2];
+      if (kM6) slab[3 * kSlabStride + blockIdx.x] = w[NACC - 1];
     }
   }
 }
@@ -1837,7 +1871,7 @@ static int sweep_segments(const mk_matrix *A, int mode, const SweepArgs &S, int 
   // Only the two CG sweeps (3 and 5 streams each) gain; SpMV+dot (x in, y out) measured 4-10 % SLOWER with the fit
   // (512^3 490 against 469 us, 27-point 256^3 159 against 144 us, banded 2^26 280 against 259 us).
   static const int fit3 = getenv("MK_SWEEP_FIT3") ? atoi(getenv("MK_SWEEP_FIT3")) : 0;   // A/B: the dots-only sweep as one round too
-  if (env_nseg <= 0 && !no_fit && (mode == 4 || mode == 5 || mode == 6 || (mode == 3 && fit3))) {
+  if (env_nseg <= 0 && !no_fit && (mode == 4 || mode == 5 || mode == 6 || mode == 7 || mode == 8 || mode == 9 || mode == 10 || (mode == 3 && fit3))) {
     const int64_t fit = (int64_t)c.num_cus * std::max(1, 1024 / S.C);
     const int64_t k = fit / S.ncp;
     if (k >= 1 && k * S.ncp * 10 >= fit * 9 && S.K / k >= 8) nseg = (int)k;
@@ -2254,12 +2288,20 @@ int launch_sweep_cg_dots(const mk_matrix *A, const double *p, double *slab_out, 
 // over the local rows, zero on the ghost-free run [gap0, gap1)
 int launch_sweep_cg_single(const mk_matrix *A, const double *r_old, double *r_new, const double *p_old, double *p_new, double *x,
                            double zscale, const double *extra, int gap0, int gap1, const double *sr_in, double *slab_out,
-                           PcgState *st, int two_norm, int rel_change, int first, int parity, double *norms, int *nblocks) {
+                           PcgState *st, int two_norm, int rel_change, int first, int parity, double *norms, int *nblocks, int xmode, int pbuf) {
   if (r_old == r_new || p_old == p_new) return fail(MK_ERR_INVALID, "single-reduction CG step: r and p are read through other blocks' windows and cannot be updated in place");
   if (!sweep_single_ok(A)) return fail(MK_ERR_UNSUPPORTED, "single-reduction CG step: not with 2048-row chunks (register budget)");
-  return launch_sweep<6>(A, zscale, p_old, 0.0, p_new, slab_out, nullptr, nblocks, r_old, extra, st, sr_in, 1, 1, x,
-                         (two_norm ? 1 : 0) | (rel_change ? 2 : 0) | (first ? 4 : 0) | ((parity & 1) << 3), norms, 0, 0, kSlabStride, r_new,
-                         (gap0 + 1) & ~1, gap1);
+  const int fl = (two_norm ? 1 : 0) | (rel_change ? 2 : 0) | (first ? 4 : 0) | ((parity & 1) << 3) | ((pbuf & 1) << 6);
+  // xmode 1 / 2: the halved solution update (launch_sweep_cg_resid_x): the step leaves x alone / adds two steps' updates
+  if (xmode == 1) return launch_sweep<9>(A, zscale, p_old, 0.0, p_new, slab_out, nullptr, nblocks, r_old, extra, st, sr_in, 1, 1, x, fl, norms, 0, 0,
+                                         kSlabStride, r_new, (gap0 + 1) & ~1, gap1);
+  if (xmode == 2) {
+    if (first) return fail(MK_ERR_INVALID, "single-reduction CG step: the first step cannot carry a pending solution update");
+    return launch_sweep<10>(A, zscale, p_old, 0.0, p_new, slab_out, nullptr, nblocks, r_old, extra, st, sr_in, 1, 1, x, fl, norms, 0, 0,
+                            kSlabStride, r_new, (gap0 + 1) & ~1, gap1);
+  }
+  return launch_sweep<6>(A, zscale, p_old, 0.0, p_new, slab_out, nullptr, nblocks, r_old, extra, st, sr_in, 1, 1, x, fl, norms, 0, 0, kSlabStride,
+                         r_new, (gap0 + 1) & ~1, gap1);
 }
 
 // the single-reduction step's kernel (MODE 6) needs ~157 VGPRs: chunks of 2048 rows (1024 threads, 128 VGPRs each) would spill
@@ -2279,9 +2321,14 @@ int launch_sweep_cg_pdots(const mk_matrix *A, const double *r, const double *p_o
 }
 
 int launch_sweep_cg_resid_x(const mk_matrix *A, const double *p, double *r, double *x, const double *dinv, const double *slab_in,
-                            int nblocks_in, int stride_in, double *slab_out, PcgState *st, int *nblocks) {
+                            int nblocks_in, int stride_in, double *slab_out, PcgState *st, int *nblocks, int xmode, int parity, int pbuf) {
   double zscale = 0.0;   // Jacobi preconditioner on a uniform diagonal: one number instead of an 8 B/row stream
   if (dinv && sweep_uniform_diag(A, &zscale)) dinv = nullptr; else zscale = 0.0;
+  const int fl = ((parity & 1) << 3) | ((pbuf & 1) << 6);
+  // xmode 1 / 2: the halved solution update (MODE 7 leaves x alone, MODE 8 adds two steps' worth); needs z = zscale r (no 1/diag stream)
+  if (xmode == 1 && !dinv) return launch_sweep<7>(A, 0.0, p, zscale, r, slab_out, nullptr, nblocks, r, dinv, st, slab_in, nblocks_in, stride_in, x, fl);
+  if (xmode == 2 && !dinv) return launch_sweep<8>(A, 0.0, p, zscale, r, slab_out, nullptr, nblocks, r, dinv, st, slab_in, nblocks_in, stride_in, x, fl);
+  if (xmode != 0) return fail(MK_ERR_INVALID, "launch_sweep_cg_resid_x: the halved solution update needs a uniform diagonal");
   return launch_sweep<4>(A, 0.0, p, zscale, r, slab_out, nullptr, nblocks, r, dinv, st, slab_in, nblocks_in, stride_in, x);
 }
 

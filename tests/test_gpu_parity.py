@@ -1202,6 +1202,52 @@ def test_pcg_3d_jacobi_precond_random_diag():
         assert np.linalg.norm(x.get() - o["x"]) <= 1e-6 * np.linalg.norm(o["x"])
 
 
+_HALFX_SNIPPET = r"""
+import sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+import iterative_solvers_amd as mk
+import oracle
+for kind, dims, precond in ((7, (32, 16, 20), 0), (27, (16, 18, 9), 1), (5, (96, 96, 1), 1)):
+    rp, ci, v = oracle.stencil_csr(kind, *dims)
+    n = rp.size - 1
+    bh = np.random.default_rng(5).normal(size=n)
+    A = mk.Matrix.from_csr(n, n, rp, ci, v)
+    A.set_spmv_kernel(mk.SPMV_SWEEP)
+    o = oracle.pcg(rp, ci, v, bh, tol=1e-9, precond=precond, maxit=1000, want_norms=True)
+    b, x = mk.Vector(n, values=bh), mk.Vector(n, fill=0.0)
+    S = mk.PCG(max_iter=1000, tol=1e-9, precond=precond, logging=1, check_every=5)
+    S.setup(A, b, x)
+    res = S.solve(A, b, x)
+    assert res["converged"] == 1 and abs(res["iterations"] - o["iterations"]) <= 2, (res, o["iterations"])
+    assert np.linalg.norm(x.get() - o["x"]) <= 1e-6 * np.linalg.norm(o["x"])
+    hist = S.residual_history(2000)
+    m = min(hist.size, o["rel_norms"].size, 40)
+    assert np.allclose(hist[:m], o["rel_norms"][:m], rtol=1e-8)
+    for k in (1, 2, 3, 6):
+        b, x = mk.Vector(n, values=bh), mk.Vector(n, fill=0.0)
+        S = mk.PCG(max_iter=k, tol=1e-30, precond=precond)
+        S.setup(A, b, x)
+        assert S.solve(A, b, x)["iterations"] == k
+        ok = oracle.pcg(rp, ci, v, bh, tol=1e-30, precond=precond, maxit=k)
+        assert np.allclose(x.get(), ok["x"], rtol=1e-9, atol=1e-13), (kind, k)
+print("halfx ok")
+"""
+
+
+@pytest.mark.parametrize("no_halved", ["0", "1"])
+def test_pcg_fused_sweep_step_halved_solution_update(no_halved):
+    """the fused CG step updates x every second step with both steps' terms (sweep MODE 7 / 8; MK_NO_HALVED_X=1: in every step).
+    Both orders against orc_pcg -- counts, history, solutions after exactly k steps for odd and even k (a solve that ends on an
+    even step applies the pending update after the loop); the switch is read once per process, hence the child processes"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MK_NO_HALVED_X=no_halved)
+    out = subprocess.run([sys.executable, "-c", _HALFX_SNIPPET, root], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0 and "halfx ok" in out.stdout, out.stderr[-3000:]
+
+
 @pytest.mark.parametrize("kind,dims", [(5, (96, 96, 1)), (7, (32, 16, 20)), (27, (16, 18, 9)), (7, (64, 32, 9)), (7, (640, 4, 6))])
 @pytest.mark.parametrize("precond", [0, 1])
 @pytest.mark.parametrize("rel_change", [0, 1])
