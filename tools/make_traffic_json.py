@@ -7,7 +7,9 @@ import collections, csv, glob, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
 # kernel slot k of the CG step bench.py times on each workload (first match wins), plus the stand-alone product
-SLOTS = {"lap7_512_cg": ["spmv_sweep_kernel<5", "spmv_sweep_kernel<4"],
+# (a slot may name several kernels that take turns in it: the halved solution update alternates MODE 7 and MODE 8; their
+# per-launch bytes are averaged over all their launches)
+SLOTS = {"lap7_512_cg": ["spmv_sweep_kernel<5", ("spmv_sweep_kernel<7", "spmv_sweep_kernel<8", "spmv_sweep_kernel<4")],
          "lap7_512_var_cg": ["spmv_vsweep_kernel<3", "pcg_update_r_kernel"]}
 EXTRA = {"lap7_512_var_cg": {"spmv_only": "spmv_vsweep_kernel<1"}}
 
@@ -34,6 +36,7 @@ out = {"what": f"rocprofv3 --pmc, one pass per counter group (FETCH_SIZE | WRITE
                "pcg_update_r_kernel; MODE 1 = the stand-alone product + dots); HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024",
        "kernels": {}}
 traffic = {}
+multi = {}
 for tag, name in (("512x512x512_0_0", "lap7_512_cg"), ("512x512x512_1_0", "lap7_512_var_cg")):
     agg = passes(f"gpurun_out/{TAG}_pmc_{tag}_*/**/pmc_counter_collection.csv") or passes(f"gpurun_out/{TAG}_pmc_{tag}_*/pmc_counter_collection.csv")
     total = 0
@@ -45,19 +48,27 @@ for tag, name in (("512x512x512_0_0", "lap7_512_cg"), ("512x512x512_1_0", "lap7_
             continue
         out["kernels"][f"{name}: {k}"] = rec
         for s, pref in enumerate(SLOTS[name]):
-            if pref in k:
+            if isinstance(pref, tuple):
+                if any(q in k for q in pref):
+                    multi.setdefault((name, s), []).append((rec["launches"], rec["hbm_bytes_per_launch"]))
+            elif pref in k:
                 traffic[f"{name}:slot{s}"] = rec["hbm_bytes_per_launch"]
                 total += rec["hbm_bytes_per_launch"]
         for key, pref in EXTRA.get(name, {}).items():
             if pref in k:
                 traffic[f"{name}:{key}"] = rec["hbm_bytes_per_launch"]
+    for (nm, s), lst in multi.items():
+        if nm == name:
+            avg = int(sum(a * b for a, b in lst) / max(1, sum(a for a, _ in lst)))
+            traffic[f"{name}:slot{s}"] = avg
+            total += avg
     traffic[f"{name}:iteration"] = total
 traffic["_note"] = ("HBM bytes per launch of kernel slot k of the CG step and per iteration, = (2*FETCH_SIZE + WRITE_SIZE) KB from separate "
                     f"rocprofv3 --pmc passes (tools/{TAG}_profiles.sh; raw values in profiles/{TAG}_pmc_cg_loops.json)")
 n, nnz = 512 ** 3, 7 * 512 ** 3 - 6 * 512 ** 2
 out["algorithmic_bytes"] = {"SURVEY 8(d) SpMV 12 nnz + 20 n + 4": 12 * nnz + 20 * n + 4, "SURVEY 8(d) CG iteration 12 nnz + 92 n": 12 * nnz + 92 * n,
                             "vsweep MODE 1 moves 8 nnz + 20 n": 8 * nnz + 20 * n, "vsweep MODE 3 with the x update moves 8 nnz + 52 n": 8 * nnz + 52 * n,
-                            "pcg_update_r_kernel 24 n": 24 * n, "sweep mode 5: 26 n": 26 * n, "sweep mode 4: 42 n": 42 * n}
+                            "pcg_update_r_kernel 24 n": 24 * n, "sweep mode 5: 26 n": 26 * n, "sweep mode 4 / 8: 42 n": 42 * n, "sweep mode 7: 26 n": 26 * n}
 json.dump(out, open(os.path.join(ROOT, f"profiles/{TAG}_pmc_cg_loops.json"), "w"), indent=1)
 json.dump(traffic, open(os.path.join(ROOT, "profiles/traffic.json"), "w"), indent=1)
 print(json.dumps(traffic, indent=1))
