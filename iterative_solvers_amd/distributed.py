@@ -277,7 +277,7 @@ def bench_main(args, rank, local_rank, world, workloads, hbm_peak):
         return float(t.item()), res
 
     # Warm-up (untimed): both forms of the CG step -- hypre_PCGSolve's two reductions per iteration (the library's default) and
-    # the single-reduction step (mk_pcg_set_single_reduction: one all-reduce of five doubles, 60 instead of 68 B per row) -- then
+    # the single-reduction step (mk_pcg_set_single_reduction: one all-reduce of five doubles, 52 instead of 68 B per row) -- then
     # a short calibration solve of each; the timed solves use the faster one (the times are maxima over the ranks, so every
     # rank picks the same).  MK_BENCH_CG_VARIANT=two|single skips the choice.
     want = os.environ.get("MK_BENCH_CG_VARIANT", "auto")
@@ -308,8 +308,8 @@ def bench_main(args, rank, local_rank, world, workloads, hbm_peak):
         # rank 0's diag block decides the byte model reported (every slab of a stencil takes the same kernel): the fused
         # sweep step moves 68 B per row and iteration (+8 with a non-uniform Jacobi diagonal), the CSR kernels the CSR model
         fused = kname == "sweep"
-        iter_bytes = (60 if use_single else 68) * n if fused else csr_bytes
-        model = (("60 B/row: two sweeps per iteration (10 B: <A r, r>; 50 B: p' = z + beta p, r -= alpha A p', x += alpha p'), A p' recomputed instead of "
+        iter_bytes = ((60 if os.environ.get("MK_NO_HALVED_X") == "1" else 52) if use_single else 68) * n if fused else csr_bytes
+        model = (("52 B/row: two sweeps per iteration (10 B: <A r, r>; 34 / 50 B: p' = z + beta p, r -= alpha A p', and every second step x += both steps' terms; 60 B/row with MK_NO_HALVED_X=1), A p' recomputed instead of "
                   "stored; halo and off-rank rows not counted" if use_single else
                   "68 B/row: two sweeps per iteration (26 B + 42 B), A p recomputed instead of stored; halo and off-rank rows not counted")
                  if fused else "CSR model: 12 nnz + 92 n (+16 n with Jacobi)")
