@@ -169,6 +169,10 @@ struct mk_matrix {
   int *gdesc = nullptr, *cdesc = nullptr;   // 16 bytes per group / per chunk: what a lane / a block loads of them (group.hip)
   int ngroups = 0, group_lanes = 0, group_cap = 0, group_ccap = 0, group_chunks = 0;
   mutable int group_bpc[2] = {0, 0};
+  // band kernel (band.hip): panels of band_rows consecutive rows whose columns lie in a window of at most band_window entries of x;
+  // band_span = (first column, entries) of every panel's window
+  int *band_span = nullptr;
+  int band_rows = 0, band_panels = 0, band_window = 0;
   double *vtab = nullptr;          // npat x pml doubles when the rows of a pattern also share their values
                                    // (pattern kernel: neither col[] nor val[] nor rowptr[] is read)
   int *otab8 = nullptr;            // pattern kernel's padded copies of ptab / vtab (row stride p8 + 8 ints, p8 doubles)
@@ -266,6 +270,10 @@ int launch_vsweep_cg_pdots(const mk_matrix *A, const double *r, const double *p_
 // rows that repeat their neighbour's column list: groups of such rows, served by spmv_group_kernel (group.hip)
 int build_row_groups(mk_matrix *A);
 int launch_group(const mk_matrix *A, int mode, double alpha, const double *x, double beta, double *y, double *slab, const int *done, int *nblocks);
+
+// rows that stay within a bounded distance of the diagonal: x window of a row panel in LDS, served by spmv_band_kernel (band.hip)
+int build_band_plan(mk_matrix *A);
+int launch_band(const mk_matrix *A, int mode, double alpha, const double *x, double beta, double *y, double *slab, const int *done, int *nblocks);
 
 int exclusive_scan_u32(const uint32_t *in, uint32_t *out, size_t n, uint32_t *total_out_dev);
 

@@ -963,6 +963,133 @@ def test_pcg_on_a_three_unknowns_per_node_matrix_through_the_row_group_kernel():
         assert np.allclose(hist[:m], o["rel_norms"][:m], rtol=1e-8)
 
 
+def _banded_matrix(rng, n, mean, hw, empty=()):
+    """rows of about `mean` entries, columns in runs of three anywhere within +-hw of the diagonal (tools/fem_probe.py's `rand`
+    shape), every entry its own value; rows in `empty` ranges have no entry"""
+    lens = rng.integers(mean * 2 // 3, mean * 4 // 3 + 1, n)
+    for a, b in empty:
+        lens[a:b] = 0
+    rp = np.concatenate([[0], np.cumsum(lens)])
+    nnz = int(rp[-1])
+    rows = np.repeat(np.arange(n), lens)
+    base = rows + rng.integers(-hw, hw + 1, nnz)
+    ci = np.clip(base - base % 3 + (np.arange(nnz) % 3), 0, n - 1)
+    ci = ci[np.lexsort((ci, rows))].astype(np.int32)
+    return rp.astype(np.int32), ci, rng.normal(size=nnz)
+
+
+class _env:
+    """environment switches the library reads per matrix (band plan), set around one construction"""
+    def __init__(self, **kw):
+        self.kw = kw
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kw}
+        os.environ.update({k: str(v) for k, v in self.kw.items()})
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("seed,n,mean,hw,empty", [
+    (1, 30000, 45, 3000, ()),                          # tools/fem_probe.py `rand 2000000 45 3000` in small: panels of 1024 rows
+    (2, 20011, 20, 700, ()),                           # odd row count: the last panel and its last chunk are partial
+    (3, 25000, 80, 400, ((5000, 5700), (24990, 25000))),   # 16 lanes per row; a panel without entries, empty rows at the end
+    (4, 9000, 30, 150, ((0, 3),)),                     # fewer rows than two of the largest panels; empty rows in front
+    (5, 12000, 100, 2000, ()),                         # rows beyond eight entries per lane (the batches of four of pass 2)
+])
+def test_spmv_band_kernel(seed, n, mean, hw, empty):
+    """VERDICT r2 item 3 (x-window staging in LDS for banded rows, band.hip): rows that share neither offsets nor column lists
+    but stay within a bounded distance of the diagonal are multiplied panel by panel with the panel's window of x in LDS.
+    Product (alpha / beta forms), product + dots and the untouched CSR arrays against the oracle, 1e-12 per row; the same
+    matrix without the plan (MK_NO_BAND) takes the stream kernel proper and agrees too."""
+    rng = np.random.default_rng(seed)
+    rp, ci, v = _banded_matrix(rng, n, mean, hw, empty)
+    with _env(MK_BAND_MIN_ROWS=1000):
+        A = mk.Matrix.from_csr(n, n, rp, ci, v)
+        i = A.info()
+    assert i.kernel == mk.SPMV_STREAM and i.index_patterns == 0 and i.row_groups == 0
+    assert 0 < i.band_window <= 2 * hw + 4096 + 3, i.band_window
+    _check_spmv(A, rp, ci, v, n, n, rng)
+    _check_spmv(A, rp, ci, v, n, n, rng, alpha=-0.75, beta=1.25)
+    _check_spmv(A, rp, ci, v, n, n, rng, alpha=2.0, beta=-1.0)
+    rp_b, ci_b, v_b = A.to_csr()
+    assert np.array_equal(rp_b, rp) and np.array_equal(ci_b, ci) and _same_bits(v_b, v)
+    xh = rng.normal(size=n)
+    x, y = mk.Vector(n, values=xh), mk.Vector(n, fill=5.0)
+    yx, xx = A.spmv_dot(x, y)
+    ref = oracle.csr_spmv(rp, ci, v, xh)
+    mag = oracle.csr_spmv(rp, ci, np.abs(v), np.abs(xh))
+    assert (np.abs(y.get() - ref) / np.maximum(mag, 1e-300)).max() <= SPMV_RTOL
+    assert abs(yx - ref @ xh) <= 1e-12 * np.abs(ref * xh).sum() and abs(xx - xh @ xh) <= 1e-12 * (xh @ xh)
+    with _env(MK_BAND_MIN_ROWS=1000, MK_NO_BAND=1):
+        B = mk.Matrix.from_csr(n, n, rp, ci, v)
+        assert B.info().band_window == 0 and B.info().kernel == mk.SPMV_STREAM
+    y2 = mk.Vector(n, fill=-1.0)
+    B.spmv(x, y2)
+    assert (np.abs(y2.get() - y.get()) / np.maximum(mag, 1e-300)).max() <= SPMV_RTOL
+    # the other kernels still serve the matrix on request
+    for k in (mk.SPMV_VECTOR, mk.SPMV_SPLIT):
+        A.set_spmv_kernel(k)
+        _check_spmv(A, rp, ci, v, n, n, rng)
+
+
+def test_spmv_band_kernel_declines_wide_rows_and_small_matrices():
+    """no plan when the window of a panel would not fit the LDS budget, when rows are short, or below the size threshold"""
+    rng = np.random.default_rng(7)
+    rp, ci, v = _banded_matrix(rng, 40000, 30, 18000)
+    with _env(MK_BAND_MIN_ROWS=1000):
+        A = mk.Matrix.from_csr(40000, 40000, rp, ci, v)
+        assert A.info().band_window == 0
+    _check_spmv(A, rp, ci, v, 40000, 40000, rng)
+    rp, ci, v = _banded_matrix(rng, 30000, 9, 300)
+    with _env(MK_BAND_MIN_ROWS=1000):
+        A = mk.Matrix.from_csr(30000, 30000, rp, ci, v)
+        assert A.info().band_window == 0          # mean row length below 16
+    with _env(MK_BAND_MIN_ROWS=1000, MK_BAND_MIN_LEN=4):
+        A = mk.Matrix.from_csr(30000, 30000, rp, ci, v)
+        assert A.info().band_window > 0
+    _check_spmv(A, rp, ci, v, 30000, 30000, rng)
+    rp, ci, v = _banded_matrix(rng, 30000, 30, 300)
+    A = mk.Matrix.from_csr(30000, 30000, rp, ci, v)
+    assert A.info().band_window == 0              # default threshold: 100 000 rows
+
+
+def test_pcg_through_the_band_kernel():
+    """CG (ids 50 and 51) on a symmetric positive definite banded matrix: K1 runs on the band kernel; iteration count, history
+    and solution against orc_pcg"""
+    rng = np.random.default_rng(12)
+    n = 24000
+    r = np.repeat(np.arange(n), 12)
+    c = np.clip(r + rng.integers(-900, 901, r.size), 0, n - 1)
+    pairs = np.unique(np.concatenate([np.stack([r, c], 1), np.stack([c, r], 1), np.stack([np.arange(n)] * 2, 1)]), axis=0)
+    r, c = pairs[:, 0], pairs[:, 1]
+    key = np.minimum(r, c) * n + np.maximum(r, c)
+    _, inv = np.unique(key, return_inverse=True)
+    w = rng.uniform(-1.0, 1.0, inv.max() + 1)[inv]
+    absum = np.bincount(r, weights=np.abs(w), minlength=n)
+    w[r == c] = 1.2 * absum[r[r == c]] + 1.0
+    rp = np.concatenate([[0], np.cumsum(np.bincount(r, minlength=n))]).astype(np.int32)
+    ci = c.astype(np.int32)
+    with _env(MK_BAND_MIN_ROWS=1000):
+        A = mk.Matrix.from_csr(n, n, rp, ci, w)
+        assert A.info().band_window > 0
+    bh = rng.normal(size=n)
+    for precond in (0, 1):
+        o = oracle.pcg(rp, ci, w, bh, tol=1e-10, precond=precond, maxit=500, want_norms=True)
+        b, x = mk.Vector(n, values=bh), mk.Vector(n, fill=0.0)
+        S = mk.PCG(max_iter=500, tol=1e-10, two_norm=1, rel_change=1, precond=precond, logging=1)
+        S.setup(A, b, x)
+        res = S.solve(A, b, x)
+        assert res["converged"] == 1 == o["converged"] and abs(res["iterations"] - o["iterations"]) <= CG_ITER_TOL
+        assert np.linalg.norm(x.get() - o["x"]) <= 1e-8 * np.linalg.norm(o["x"])
+        hist = S.residual_history(1000)
+        m = min(hist.size, o["rel_norms"].size, 30)
+        assert np.allclose(hist[:m], o["rel_norms"][:m], rtol=1e-8)
+
+
 @pytest.mark.parametrize("dof,nx,ny", [(2, 37, 23), (4, 20, 31)])
 def test_spmv_pattern_shapes_short_rows(dof, nx, ny):
     """several unknowns per node of a 2-D 5-point grid, every entry its own value: the index patterns of a node's rows differ

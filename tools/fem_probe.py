@@ -92,8 +92,15 @@ def run(name, n, rp, ci):
     mk.synchronize(); t_an = (time.perf_counter() - t0) * 1e3
     x, y = mk.Vector(n, fill=1.0), mk.Vector(n)
     b = 12 * nnz + 20 * n + 4
-    out = [f"{name}: rows {n} mean {nnz / n:.1f} max {i.max_row_len} default {i.kernel} patterns {i.index_patterns} lanes {i.stream_lanes} chunk {i.stream_chunk} shared {i.shared_columns / max(nnz, 1):.2f} groups {i.row_groups} glanes {i.group_lanes} analysis {t_an:.2f} ms |"]
-    for k in (0, 1, 2, 3):
+    out = [f"{name}: rows {n} mean {nnz / n:.1f} max {i.max_row_len} default {i.kernel} patterns {i.index_patterns} lanes {i.stream_lanes} chunk {i.stream_chunk} shared {i.shared_columns / max(nnz, 1):.2f} groups {i.row_groups} glanes {i.group_lanes} window {i.band_window} analysis {t_an:.2f} ms |"]
+    cases = [(0, A, "k0"), (1, A, "k1"), (2, A, "k2"), (3, A, "k3")]
+    if i.band_window > 0:   # the same matrix without the band plan: the stream kernel proper
+        os.environ["MK_NO_BAND"] = "1"
+        B = mk.Matrix.from_csr(n, n, rp, ci, v)
+        B.info()
+        del os.environ["MK_NO_BAND"]
+        cases.append((2, B, "k2-noband"))
+    for k, A, label in cases:
         try:
             A.set_spmv_kernel(k)
         except mk.MkError:
@@ -104,7 +111,7 @@ def run(name, n, rp, ci):
         for _ in range(20):
             A.spmv(x, y)
         ms = mk.timer_stop() / 20
-        out.append(f"k{k} {ms * 1e3:.0f} us {b / ms / 1e6 / 8000:.3f}")
+        out.append(f"{label} {ms * 1e3:.0f} us {b / ms / 1e6 / 8000:.3f}")
     print(" ".join(out), flush=True)
 
 
