@@ -128,8 +128,8 @@ typedef struct {
   int64_t row_groups;      /* > 0: MK_SPMV_STREAM serves the product group by group (runs of up to 4 consecutive rows with one
                               column list): x is gathered once per list and multiplied with every row of the group */
   int32_t group_lanes;     /* ... with this many lanes per group */
-  int32_t band_window;     /* > 0: MK_SPMV_STREAM serves the product panel by panel with the panel's window of x (at most this many
-                              entries) staged in LDS: rows that stay within a bounded distance of the diagonal (band kernel) */
+  int32_t band_window;     /* > 0: MK_SPMV_STREAM serves the product with a sliding window of x (this many entries) kept in LDS:
+                              rows that stay within a bounded distance of the diagonal (band kernel) */
 } mk_matrix_info;
 int mk_matrix_get_info(const mk_matrix *A, mk_matrix_info *info);
 

@@ -169,10 +169,11 @@ struct mk_matrix {
   int *gdesc = nullptr, *cdesc = nullptr;   // 16 bytes per group / per chunk: what a lane / a block loads of them (group.hip)
   int ngroups = 0, group_lanes = 0, group_cap = 0, group_ccap = 0, group_chunks = 0;
   mutable int group_bpc[2] = {0, 0};
-  // band kernel (band.hip): panels of band_rows consecutive rows whose columns lie in a window of at most band_window entries of x;
-  // band_span = (first column, entries) of every panel's window
-  int *band_span = nullptr;
-  int band_rows = 0, band_panels = 0, band_window = 0;
+  // band kernel (band.hip): chunks of band_rows consecutive rows whose columns lie within band_window entries behind the running
+  // maximum column; band_desc = 16 bytes per chunk (first entry, running maximum, first new column, 0), band_bstart = first chunk
+  // of each of the band_blocks blocks
+  int *band_desc = nullptr, *band_bstart = nullptr;
+  int band_rows = 0, band_chunks = 0, band_blocks = 0, band_window = 0;
   double *vtab = nullptr;          // npat x pml doubles when the rows of a pattern also share their values
                                    // (pattern kernel: neither col[] nor val[] nor rowptr[] is read)
   int *otab8 = nullptr;            // pattern kernel's padded copies of ptab / vtab (row stride p8 + 8 ints, p8 doubles)
