@@ -607,7 +607,9 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import fem_probe
             import numpy as np
-            for fname, (fn, rp, ci) in (("fem_hex3_64", fem_probe.hex3(64)), ("fem_rand3_500k", fem_probe.rand3(500000, 26, 300))):
+            # ... and rows that share nothing but stay within 3000 columns of the diagonal (band kernel: sliding x window in LDS)
+            for fname, (fn, rp, ci) in (("fem_hex3_64", fem_probe.hex3(64)), ("fem_rand3_500k", fem_probe.rand3(500000, 26, 300)),
+                                        ("fem_rand_band_600k", fem_probe.rand(600000, 45, 3000))):
                 vals = np.random.default_rng(0).normal(size=ci.size)
                 A4 = mk.Matrix.from_csr(fn, fn, rp, ci, vals)
                 i4 = A4.info()
@@ -623,7 +625,7 @@ def main():
                               "spmv_ms": round(ms4, 4), "spmv_frac": round(b4 / (ms4 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                               "spmv_bytes_model": "SURVEY 8(d): 12 nnz + 20 n + 4", "spmv_kernel": KERNEL_NAMES.get(i4.kernel),
                               "index_patterns": i4.index_patterns, "shared_column_entries": i4.shared_columns,
-                              "row_groups": i4.row_groups, "group_lanes": i4.group_lanes,
+                              "row_groups": i4.row_groups, "group_lanes": i4.group_lanes, "band_window": i4.band_window,
                               "stream_lanes": i4.stream_lanes, "stream_chunk": i4.stream_chunk}
                 del A4, x4, y4, vals
         except Exception as e:      # never lose the headline to a secondary measurement
