@@ -130,6 +130,9 @@ typedef struct {
   int32_t group_lanes;     /* ... with this many lanes per group */
   int32_t band_window;     /* > 0: MK_SPMV_STREAM serves the product with a sliding window of x (this many entries) kept in LDS:
                               rows that stay within a bounded distance of the diagonal (band kernel) */
+  int32_t band_strips;     /* > 0: ... as that many diagonal strips (entries grouped by column - row), one band-kernel launch each:
+                              rows that reach further than one LDS window */
+  int32_t reserved1;
 } mk_matrix_info;
 int mk_matrix_get_info(const mk_matrix *A, mk_matrix_info *info);
 

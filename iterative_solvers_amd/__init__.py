@@ -36,7 +36,7 @@ class MatrixInfo(C.Structure):
                 ("hist", C.c_int64 * 16), ("kernel", C.c_int32), ("lanes_per_row", C.c_int32),
                 ("long_rows", C.c_int64), ("index_patterns", C.c_int64), ("value_patterns", C.c_int64),
                 ("stream_lanes", C.c_int32), ("stream_chunk", C.c_int32), ("shared_columns", C.c_int64),
-                ("row_groups", C.c_int64), ("group_lanes", C.c_int32), ("band_window", C.c_int32)]
+                ("row_groups", C.c_int64), ("group_lanes", C.c_int32), ("band_window", C.c_int32), ("band_strips", C.c_int32), ("reserved1", C.c_int32)]
 
 
 SPMV_AUTO, SPMV_VECTOR, SPMV_STREAM, SPMV_SPLIT, SPMV_PATTERN, SPMV_SWEEP, SPMV_VSWEEP = 0, 1, 2, 3, 4, 5, 6

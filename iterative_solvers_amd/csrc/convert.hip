@@ -548,7 +548,10 @@ static void free_coo_buffers(mk_coo *d) {
 
 static void free_matrix_buffers(mk_matrix *A) {
   dev_free(A->rowptr); dev_free(A->col); dev_free(A->val); dev_free(A->dinv);
-  dev_free(A->chunk_row); dev_free(A->long_rows); dev_free(A->carry); dev_free(A->pat); dev_free(A->ptab); dev_free(A->stab); dev_free(A->colc); dev_free(A->cptr); dev_free(A->rowpair); dev_free(A->grow); dev_free(A->gcol); dev_free(A->gdesc); dev_free(A->cdesc); dev_free(A->band_desc); dev_free(A->band_bstart); dev_free(A->vtab); dev_free(A->otab8); dev_free(A->vtab8); dev_free(A->pmask); dev_free(A->etab); dev_free(A->sweep_perm); delete A->sweep;
+  dev_free(A->chunk_row); dev_free(A->long_rows); dev_free(A->carry); dev_free(A->pat); dev_free(A->ptab); dev_free(A->stab); dev_free(A->colc); dev_free(A->cptr); dev_free(A->rowpair); dev_free(A->grow); dev_free(A->gcol); dev_free(A->gdesc); dev_free(A->cdesc); dev_free(A->band_desc); dev_free(A->band_bstart);
+  for (int q = 0; q < A->nstrips; q++) { if (A->strips[q]) { free_matrix_buffers(A->strips[q]); delete A->strips[q]; A->strips[q] = nullptr; } }
+  A->nstrips = 0;
+  dev_free(A->vtab); dev_free(A->otab8); dev_free(A->vtab8); dev_free(A->pmask); dev_free(A->etab); dev_free(A->sweep_perm); delete A->sweep;
   dev_free(A->col2); dev_free(A->xg); dev_free(A->xorder);
 }
 

@@ -173,7 +173,11 @@ struct mk_matrix {
   // maximum column; band_desc = 16 bytes per chunk (first entry, running maximum, first new column, 0), band_bstart = first chunk
   // of each of the band_blocks blocks
   int *band_desc = nullptr, *band_bstart = nullptr;
-  int band_rows = 0, band_chunks = 0, band_blocks = 0, band_window = 0;
+  int band_rows = 0, band_chunks = 0, band_blocks = 0, band_window = 0, band_lanes = 0, band_cap = 0;
+  // ... or, when one window would not fit the LDS, the matrix cut into nstrips diagonal strips (CSR matrices of their own, each
+  // with its band plan; band.hip build_strips)
+  mk_matrix *strips[12] = {};
+  int nstrips = 0;
   double *vtab = nullptr;          // npat x pml doubles when the rows of a pattern also share their values
                                    // (pattern kernel: neither col[] nor val[] nor rowptr[] is read)
   int *otab8 = nullptr;            // pattern kernel's padded copies of ptab / vtab (row stride p8 + 8 ints, p8 doubles)

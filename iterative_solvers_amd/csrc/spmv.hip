@@ -669,7 +669,8 @@ int analyse_matrix(mk_matrix *A) {
   I.shared_columns = A->cptr ? A->nnz - A->colc_len : 0;
   I.row_groups = A->grow ? A->ngroups : 0;
   I.group_lanes = A->grow ? A->group_lanes : 0;
-  I.band_window = A->band_desc ? A->band_window : 0;
+  I.band_window = (A->band_desc || A->nstrips) ? A->band_window : 0;
+  I.band_strips = A->nstrips;
   A->analysed = true;
   return MK_OK;
 }
@@ -2241,7 +2242,7 @@ int launch_spmv(const mk_matrix *A, double alpha, const double *x, double beta, 
   if (A->kernel == MK_SPMV_SWEEP) return launch_sweep<0>(A, alpha, x, beta, y, nullptr, skip, nullptr);
   if (A->kernel == MK_SPMV_PATTERN) return launch_pattern<0>(A, alpha, x, beta, y, nullptr, skip, nullptr);
   if (A->kernel == MK_SPMV_STREAM && A->grow) return launch_group(A, 0, alpha, x, beta, y, nullptr, skip, nullptr);
-  if (A->kernel == MK_SPMV_STREAM && A->band_desc) return launch_band(A, 0, alpha, x, beta, y, nullptr, skip, nullptr);
+  if (A->kernel == MK_SPMV_STREAM && (A->band_desc || A->nstrips)) return launch_band(A, 0, alpha, x, beta, y, nullptr, skip, nullptr);
   if (A->kernel == MK_SPMV_STREAM) return launch_stream<0>(A, alpha, x, beta, y, nullptr, skip, nullptr);
   if (A->kernel == MK_SPMV_SPLIT) return launch_split<0>(A, alpha, x, beta, y, nullptr, skip, nullptr);
   return launch_vector<0>(A, alpha, x, beta, y, nullptr, skip, nullptr);
@@ -2341,7 +2342,7 @@ int launch_spmv_dot(const mk_matrix *A, const double *x, double *y, double *slab
   if (A->kernel == MK_SPMV_SWEEP) return launch_sweep<1>(A, 1.0, x, 0.0, y, slab, done, nblocks);
   if (A->kernel == MK_SPMV_PATTERN) return launch_pattern<1>(A, 1.0, x, 0.0, y, slab, done, nblocks);
   if (A->kernel == MK_SPMV_STREAM && A->grow) return launch_group(A, 1, 1.0, x, 0.0, y, slab, done, nblocks);
-  if (A->kernel == MK_SPMV_STREAM && A->band_desc) return launch_band(A, 1, 1.0, x, 0.0, y, slab, done, nblocks);
+  if (A->kernel == MK_SPMV_STREAM && (A->band_desc || A->nstrips)) return launch_band(A, 1, 1.0, x, 0.0, y, slab, done, nblocks);
   if (A->kernel == MK_SPMV_STREAM) return launch_stream<1>(A, 1.0, x, 0.0, y, slab, done, nblocks);
   if (A->kernel == MK_SPMV_SPLIT) return launch_split<1>(A, 1.0, x, 0.0, y, slab, done, nblocks);
   return launch_vector<1>(A, 1.0, x, 0.0, y, slab, done, nblocks);

@@ -1011,7 +1011,7 @@ def test_spmv_band_kernel(seed, n, mean, hw, empty):
         A = mk.Matrix.from_csr(n, n, rp, ci, v)
         i = A.info()
     assert i.kernel == mk.SPMV_STREAM and i.index_patterns == 0 and i.row_groups == 0
-    assert 0 < i.band_window <= 2 * hw + 4096 + 3, i.band_window
+    assert 0 < i.band_window <= 2 * hw + 4096 + 3 and i.band_strips == 0, (i.band_window, i.band_strips)
     _check_spmv(A, rp, ci, v, n, n, rng)
     _check_spmv(A, rp, ci, v, n, n, rng, alpha=-0.75, beta=1.25)
     _check_spmv(A, rp, ci, v, n, n, rng, alpha=2.0, beta=-1.0)
@@ -1034,6 +1034,60 @@ def test_spmv_band_kernel(seed, n, mean, hw, empty):
     for k in (mk.SPMV_VECTOR, mk.SPMV_SPLIT):
         A.set_spmv_kernel(k)
         _check_spmv(A, rp, ci, v, n, n, rng)
+
+
+@pytest.mark.parametrize("seed,n,mean,hw,empty", [
+    (1, 60000, 80, 12000, ()),                         # tools/fem_probe.py `rand 1500000 80 20000` in small: 5 strips
+    (2, 50001, 64, 8000, ((100, 400), (49990, 50001))),   # 3 strips; empty rows; odd row count
+    (3, 40000, 130, 30000, ()),                        # 12 strips, the most there are
+])
+def test_spmv_band_kernel_diagonal_strips(seed, n, mean, hw, empty):
+    """rows that reach further than one LDS window: the matrix is cut into diagonal strips (entries grouped by column - row),
+    each served by the band kernel, y accumulated strip by strip; the dots ride in the last strip's launch.  Against the
+    oracle on the CSR as given, 1e-12 per row (the row's sum is formed strip by strip: another order, still a fixed one)."""
+    rng = np.random.default_rng(seed)
+    rp, ci, v = _banded_matrix(rng, n, mean, hw, empty)
+    with _env(MK_BAND_MIN_ROWS=1000):
+        A = mk.Matrix.from_csr(n, n, rp, ci, v)
+        i = A.info()
+    assert i.kernel == mk.SPMV_STREAM and i.band_strips >= 2 and 0 < i.band_window < 8000, (i.band_strips, i.band_window)
+    assert i.band_strips == -(-(2 * hw + 3) // 5400) or i.band_strips == -(-(2 * hw + 1) // 5400), i.band_strips
+    _check_spmv(A, rp, ci, v, n, n, rng)
+    _check_spmv(A, rp, ci, v, n, n, rng, alpha=-0.75, beta=1.25)
+    _check_spmv(A, rp, ci, v, n, n, rng, alpha=2.0, beta=-1.0)
+    rp_b, ci_b, v_b = A.to_csr()
+    assert np.array_equal(rp_b, rp) and np.array_equal(ci_b, ci) and _same_bits(v_b, v)
+    xh = rng.normal(size=n)
+    x, y = mk.Vector(n, values=xh), mk.Vector(n, fill=5.0)
+    yx, xx = A.spmv_dot(x, y)
+    ref = oracle.csr_spmv(rp, ci, v, xh)
+    mag = oracle.csr_spmv(rp, ci, np.abs(v), np.abs(xh))
+    assert (np.abs(y.get() - ref) / np.maximum(mag, 1e-300)).max() <= SPMV_RTOL
+    assert abs(yx - ref @ xh) <= 1e-12 * np.abs(ref * xh).sum() and abs(xx - xh @ xh) <= 1e-12 * (xh @ xh)
+    y1 = y.get().copy()
+    A.spmv_dot(x, y)
+    assert _same_bits(y.get(), y1)                     # the same bits from run to run
+    with _env(MK_BAND_MIN_ROWS=1000, MK_NO_BAND_STRIPS=1):     # without strips: one window with one block per CU where that fits, else the stream kernel
+        B = mk.Matrix.from_csr(n, n, rp, ci, v)
+        ib = B.info()
+        assert ib.band_strips == 0 and (ib.band_window == 0 or ib.band_window > 2 * hw)
+    y2 = mk.Vector(n, fill=-1.0)
+    B.spmv(x, y2)
+    assert (np.abs(y2.get() - y1) / np.maximum(mag, 1e-300)).max() <= SPMV_RTOL
+
+
+def test_spmv_band_kernel_one_block_per_cu_window():
+    """a window beyond half a CU's LDS on rows too short for strips (fewer than six entries per row and strip): one window, one
+    block per CU"""
+    rng = np.random.default_rng(21)
+    n = 60000
+    rp, ci, v = _banded_matrix(rng, n, 17, 6000)   # (about 16.5 entries per row: above the kernel's threshold of 16, below 3 strips x 6)
+    with _env(MK_BAND_MIN_ROWS=1000):
+        A = mk.Matrix.from_csr(n, n, rp, ci, v)
+        i = A.info()
+    assert i.band_strips == 0 and 12000 < i.band_window < 14000, (i.band_strips, i.band_window)
+    _check_spmv(A, rp, ci, v, n, n, rng)
+    _check_spmv(A, rp, ci, v, n, n, rng, alpha=0.5, beta=2.0)
 
 
 def test_spmv_band_kernel_declines_wide_rows_and_small_matrices():

@@ -92,7 +92,7 @@ def run(name, n, rp, ci):
     mk.synchronize(); t_an = (time.perf_counter() - t0) * 1e3
     x, y = mk.Vector(n, fill=1.0), mk.Vector(n)
     b = 12 * nnz + 20 * n + 4
-    out = [f"{name}: rows {n} mean {nnz / n:.1f} max {i.max_row_len} default {i.kernel} patterns {i.index_patterns} lanes {i.stream_lanes} chunk {i.stream_chunk} shared {i.shared_columns / max(nnz, 1):.2f} groups {i.row_groups} glanes {i.group_lanes} window {i.band_window} analysis {t_an:.2f} ms |"]
+    out = [f"{name}: rows {n} mean {nnz / n:.1f} max {i.max_row_len} default {i.kernel} patterns {i.index_patterns} lanes {i.stream_lanes} chunk {i.stream_chunk} shared {i.shared_columns / max(nnz, 1):.2f} groups {i.row_groups} glanes {i.group_lanes} window {i.band_window} strips {i.band_strips} analysis {t_an:.2f} ms |"]
     cases = [(0, A, "k0"), (1, A, "k1"), (2, A, "k2"), (3, A, "k3")]
     if i.band_window > 0:   # the same matrix without the band plan: the stream kernel proper
         os.environ["MK_NO_BAND"] = "1"
@@ -105,11 +105,12 @@ def run(name, n, rp, ci):
             A.set_spmv_kernel(k)
         except mk.MkError:
             continue
+        beta = float(os.environ.get("FEM_PROBE_BETA", "0"))   # (y = A x + beta y: the accumulating form reads y as well)
         for _ in range(3):
-            A.spmv(x, y)
+            A.spmv(x, y, 1.0, beta)
         mk.timer_start()
         for _ in range(20):
-            A.spmv(x, y)
+            A.spmv(x, y, 1.0, beta)
         ms = mk.timer_stop() / 20
         out.append(f"{label} {ms * 1e3:.0f} us {b / ms / 1e6 / 8000:.3f}")
     print(" ".join(out), flush=True)
