@@ -4,13 +4,15 @@
 // neither offsets (no pattern table) nor column lists (no row groups): finite-element matrices in a bandwidth-reducing
 // order.  The stream kernel gathers x per entry from global memory, and what bounds it there is the number of L1 -> L2
 // requests of those gathers, not HBM (0.34-0.46 of the roofline on tools/fem_probe.py's `rand` cases).  Here
-//   chunk  = 512 / G consecutive rows (the stream kernel's chunk for the same lanes per row);
-//   block  = a contiguous run of chunks holding about nnz / blocks entries;
+//   chunk  = up to 512 / G consecutive rows (G lanes per row from the mean row length), fewer where that many rows would
+//            overflow the product stage;
+//   block  = a contiguous run of chunks of about equal cost (entries + an average chunk's entries per chunk);
 //   window = the last M columns up to the largest column any chunk so far has touched (H_k, a running maximum over the
 //            whole matrix, so it only moves forward), kept in an LDS ring of M doubles (slot = column mod M).  A block
 //            fills the ring once at its start; every chunk then adds only the columns its successor brings in
 //            (H_k, H_k+1], loaded one chunk ahead.  M = the largest H_k - (smallest column of chunk k) + 1: the plan
-//            exists when M doubles and the product stage fit half a CU's LDS (or all of it, with one block per CU);
+//            exists when M doubles and the product stage fit half a CU's LDS; a matrix that needs more is cut into diagonal
+//            strips (build_strips below), each with a plan of its own; last resort: one window, one block per CU;
 //   pass 1 reads the chunk's (value, column) pairs with coalesced 16- and 8-byte loads requested ahead of their use
 //            (two register sets; measured: how far ahead does not matter), multiplies every value with its x
 //            from the ring and leaves the products in LDS; pass 2 gives every row G lanes that add the row's products (lane g: entries g, g + G, ..., then a
