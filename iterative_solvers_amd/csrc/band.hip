@@ -583,7 +583,8 @@ int launch_band(const mk_matrix *A, int mode, double alpha, const double *x, dou
 static int launch_band_one(const mk_matrix *A, int mode, double alpha, const double *x, double beta, double *y, double *slab, const int *done, int *nblocks, int acc) {
   if (!A->band_desc || !A->band_bstart || A->band_lanes < 2 || A->band_rows != kBThreads / A->band_lanes || A->band_blocks < 8 || (A->band_blocks & 7))
     return fail(MK_ERR_UNSUPPORTED, "spmv: the band kernel needs a matrix whose rows stay within a bounded window of x");
-  const bool nt = nt_matrix((double)std::max<int64_t>(A->nnz, A->info.nnz) * 8.0);
+  static const int env_nt = getenv("MK_BAND_NT") ? atoi(getenv("MK_BAND_NT")) : -1;   // (tuning: 0 / 1 forces plain / nontemporal matrix loads)
+  const bool nt = env_nt >= 0 ? env_nt != 0 : nt_matrix((double)std::max<int64_t>(A->nnz, A->info.nnz) * 8.0);
   const int cap = A->band_cap;
 #define MK_BAND_PICK(UU)                                                                                     \
   if (cap <= 1024 * UU - 8) {                                                                                \
