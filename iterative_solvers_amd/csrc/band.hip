@@ -364,6 +364,8 @@ __global__ __launch_bounds__(kBThreads) void spmv_band_kernel(
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   double *xw = reinterpret_cast<double *>(smem_raw);            // M doubles: the ring, slot = column mod M
   double *sprod = reinterpret_cast<double *>(smem_raw) + M;     // cap + 2 doubles: the chunk's products (M is a multiple of 8)
+  const int zslot = cap + 2;                                    // ... then a zero no store reaches (read for lanes behind their row's end)
+  if (threadIdx.x == 0) sprod[zslot] = 0.0;                     // (visible after the first barrier)
   const int tid = threadIdx.x;
   const int g = tid % G, rl = tid / G;
   // blocks of one XCD (equal blockIdx % 8) take neighbouring runs of chunks: their windows overlap in that XCD's L2
@@ -440,29 +442,30 @@ __global__ __launch_bounds__(kBThreads) void spmv_band_kernel(
       const bool have_row = row < d1.w;
       const int b = nb_ - vb, e = ne_ - vb;
       const double xr = nxr, yold = nyold;
-      row_loads(j + 1, d1.w, d2.w);
       const bi4_t d4 = cdesc[j + 4];
-      // pass 1: products of the staged pairs; an entry outside the chunk (the odd one a 16-byte load drags in) must not
-      // index the ring with a column of another window
-      bd2_t pr[U];
+      // pass 1: products of the staged pairs.  No per-entry predicates: the two entries a pair may hold from outside the chunk
+      // (the odd one in front that a 16-byte load drags in, the one behind the end) are multiplied like the others, with their
+      // ring index clamped into the ring, and land in stage slots no row reads (pass 2 reads [b, e) of its rows only).  What
+      // bounds this kernel is its instruction count, so every select per entry counts.
+      {
+        const unsigned npairs_cur = (unsigned)(ce - vb + 1) >> 1;
+        bd2_t *spairs = reinterpret_cast<bd2_t *>(sprod);
 #pragma unroll
-      for (int i = 0; i < U; i++) {
-        const int k = vb + (tid + i * kBThreads) * 2;
-        pr[i].x = 0.0;
-        pr[i].y = 0.0;
-        if (k < ce) {
-          const unsigned s0 = (k >= cb) ? slot_of(S.rc[i].x, rb) : 0u;
-          const unsigned s1 = (k + 1 < ce) ? slot_of(S.rc[i].y, rb) : 0u;
-          const double x0 = xw[s0], x1 = xw[s1];
-          pr[i].x = (k >= cb) ? S.rv[i].x * x0 : 0.0;
-          pr[i].y = (k + 1 < ce) ? S.rv[i].y * x1 : 0.0;
+        for (int i = 0; i < U; i++) {
+          const unsigned pi = (unsigned)tid + (unsigned)(i * kBThreads);
+          if (pi < npairs_cur) {
+            const unsigned s0 = min(slot_of(S.rc[i].x, rb), uM - 1u);
+            const unsigned s1 = min(slot_of(S.rc[i].y, rb), uM - 1u);
+            bd2_t pr;
+            pr.x = S.rv[i].x * xw[s0];
+            pr.y = S.rv[i].y * xw[s1];
+            spairs[pi] = pr;
+          }
         }
       }
-#pragma unroll
-      for (int i = 0; i < U; i++) {
-        const int k = vb + (tid + i * kBThreads) * 2;
-        if (k < ce) *reinterpret_cast<bd2_t *>(sprod + (k - vb)) = pr[i];
-      }
+      // (requested here, behind pass 1: the wait in front of pass 1 cannot be counted -- predicated loads -- so it waits for
+      // every load in flight, and a load requested at the top of the step would put its round trip into every step)
+      row_loads(j + 1, d1.w, d2.w);
       // chunk j + 2: its pairs and its new ring column
       if (j + 2 < k1) {
         pair_loads(S, d2.x, d3.x);
@@ -478,24 +481,18 @@ __global__ __launch_bounds__(kBThreads) void spmv_band_kernel(
         for (int o2 = o + kBThreads; o2 <= d1.y; o2 += kBThreads) xw[slot_of(o2, rbn)] = x[o2];   // (a jump of more than 512 columns)
       }
       // pass 2: G lanes per row
+      // (a lane behind its row's end reads the stage's zero slot: one 32-bit select instead of a 64-bit one and a clamp; slots
+      // no lane of the wave needs are skipped by a wave-uniform branch)
       double sum = 0.0;
       {
-        const int lastj = max(e - 1, 0);
-        double pj[8];
+        const int ee = have_row ? e : 0;
+        const int q0 = (have_row ? b : 0) + g;   // (a lane without a row must not count as "in front of its end": its b is not a stage index)
 #pragma unroll
         for (int t = 0; t < 8; t++) {
-          const int q = b + g + t * G;
-          pj[t] = (have_row && q < e) ? sprod[min(q, lastj)] : 0.0;
+          const int q = q0 + t * G;
+          if (__any(q < ee)) sum += sprod[q < ee ? q : zslot];
         }
-#pragma unroll
-        for (int t = 0; t < 8; t++) sum += pj[t];
-        for (int q0 = b + g + 8 * G; have_row && q0 < e; q0 += 4 * G) {
-          double p4[4];
-#pragma unroll
-          for (int t = 0; t < 4; t++) p4[t] = (q0 + t * G < e) ? sprod[min(q0 + t * G, lastj)] : 0.0;
-#pragma unroll
-          for (int t = 0; t < 4; t++) sum += p4[t];
-        }
+        for (int q = q0 + 8 * G; __any(q < ee); q += G) sum += sprod[q < ee ? q : zslot];
       }
       if (G > 1) sum = group_sum<G>(sum);
       if (g == 0 && have_row) {
