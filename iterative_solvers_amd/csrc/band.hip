@@ -25,6 +25,12 @@
 namespace mk {
 
 constexpr int kBThreads = 512;
+// A chunk's loads start at the last multiple of 32 entries in front of its first entry: 256 bytes of values, 128 of columns, so
+// that every wave's load covers whole cache lines.  Measured (tools/microbench/read_stream.hip): two streams read side by side
+// at 7.06 TB/s when they start on a line, at 5.41 TB/s when they start 40 / 20 bytes off one -- which is where a chunk of a CSR
+// matrix starts.  The up to 31 entries in front are the previous chunk's (an L2 hit), multiplied with clamped ring indices into
+// stage slots no row reads.
+constexpr int kBandAlign = 32;
 typedef double bd2_t __attribute__((ext_vector_type(2)));
 typedef int bi2_t __attribute__((ext_vector_type(2)));
 typedef int bi4_t __attribute__((ext_vector_type(4)));
@@ -74,7 +80,7 @@ static int plan_band(mk_matrix *A, int64_t *need_out, int lds_budget) {
   MK_HIP(hipMemcpyAsync(rp.data(), A->rowptr, sizeof(int) * rp.size(), hipMemcpyDeviceToHost, c.stream));
   MK_HIP(hipStreamSynchronize(c.stream));
   // the stage: a quarter above the average chunk of R rows, at most the 4 x 1024 - 8 entries a thread's loads can fill
-  const int cap_lim = (int)std::min<int64_t>(4080, std::max<int64_t>(1016, (int64_t)(1.25 * R * A->info.mean_row_len) + 64));
+  const int cap_lim = (int)std::min<int64_t>(4080 - kBandAlign, std::max<int64_t>(1016, (int64_t)(1.25 * R * A->info.mean_row_len) + 64));
   std::vector<int> crow;
   crow.reserve((size_t)(A->nrows / R) * 5 / 4 + 16);
   int fullest = 64;
@@ -116,7 +122,7 @@ static int plan_band(mk_matrix *A, int64_t *need_out, int lds_budget) {
     if (H < 0) return MK_OK;
   }
   if (need_out) *need_out = need;
-  const int cap = (fullest + 3) & ~3;
+  const int cap = ((fullest + 3) & ~3) + kBandAlign;   // (the stage holds the entries in front of the chunk, back to the aligned start, as well)
   const int64_t M = (need + 7) & ~(int64_t)7;
   const int64_t lds = (M + cap + 4) * 8;
   // the window must fit beside the product stage; a window of more than 64 entries per row of the chunk is a matrix whose
@@ -380,7 +386,7 @@ __global__ __launch_bounds__(kBThreads) void spmv_band_kernel(
   // Addresses: a block-uniform base (scalar registers) plus the thread's own 32-bit pair index.  Lanes behind the end of the
   // chunk load nothing (whole waves skip their loads and their part of pass 1).
   auto pair_loads = [&](BandSet<U> &S, int cb_, int ce_) {
-    const int vb_ = cb_ & ~1;
+    const int vb_ = cb_ & ~(kBandAlign - 1);
     const unsigned npairs = (unsigned)(ce_ - vb_ + 1) >> 1;
     const bd2_t *vbase = reinterpret_cast<const bd2_t *>(val + vb_);
     const bi2_t *cbase = reinterpret_cast<const bi2_t *>(col + vb_);
@@ -436,7 +442,7 @@ __global__ __launch_bounds__(kBThreads) void spmv_band_kernel(
     int j = k0;
     // one chunk: S holds its pairs (and is refilled with chunk j + 2's), T holds chunk j + 1's new ring column
     auto step = [&](BandSet<U> &S, BandSet<U> &T) {
-      const int cb = d0.x, ce = d1.x, vb = cb & ~1;
+      const int cb = d0.x, ce = d1.x, vb = cb & ~(kBandAlign - 1);
       while (d0.y + 1 - M >= rb + M) rb += M;   // (block-uniform)
       const int64_t row = (int64_t)d0.w + rl;
       const bool have_row = row < d1.w;

@@ -36,6 +36,68 @@ __global__ __launch_bounds__(T) void k_read(const d2 *__restrict__ a, size_t nve
   if (acc == 12345.678) out[0] = acc;   // (never true: keeps the loads alive)
 }
 
+// Two streams read side by side as the CSR kernels read val[] and col[]: per step ILP 16-byte loads from a and ILP loads of
+// W bytes (8 or 16) per lane from b, every block streaming its own contiguous ranges of both (ORDER 1).  W = 16 reads b in
+// tiles half as long, so that both forms move 1.5 x the bytes of a alone.  PAIR32: the 16-byte loads of a leave as two per
+// lane from ADJACENT addresses (lane stride 32 bytes) instead of lane-consecutive ones.
+typedef int i2 __attribute__((ext_vector_type(2)));
+typedef int i4 __attribute__((ext_vector_type(4)));
+template <int T, int ILP, int W, bool PAIR32>
+__global__ __launch_bounds__(T) void k_two(const d2 *__restrict__ a, const int *__restrict__ b, size_t nvec, double *__restrict__ out) {
+  const size_t tile = (size_t)T * ILP;   // 16-byte vectors of a per step
+  const size_t per = nvec / tile / gridDim.x;
+  double acc = 0.0;
+  for (size_t s = 0; s < per; s++) {
+    const size_t t0 = ((size_t)blockIdx.x * per + s) * tile;   // first vector of the tile in a; b holds 2 ints per vector of a
+    d2 v[ILP];
+    int c[ILP * 2];
+    if (PAIR32) {
+#pragma unroll
+      for (int i = 0; i < ILP; i += 2) {
+        const d2 *p = a + t0 + (size_t)i * T + 2 * threadIdx.x;
+        v[i] = __builtin_nontemporal_load(p);
+        v[i + 1] = __builtin_nontemporal_load(p + 1);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < ILP; i++) v[i] = __builtin_nontemporal_load(a + t0 + (size_t)i * T + threadIdx.x);
+    }
+    if (W == 8) {
+#pragma unroll
+      for (int i = 0; i < ILP; i++) {
+        const i2 q = __builtin_nontemporal_load(reinterpret_cast<const i2 *>(b) + t0 + (size_t)i * T + threadIdx.x);
+        c[2 * i] = q.x; c[2 * i + 1] = q.y;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < ILP / 2; i++) {
+        const i4 q = __builtin_nontemporal_load(reinterpret_cast<const i4 *>(b) + t0 / 2 + (size_t)i * T + threadIdx.x);
+        c[4 * i] = q.x; c[4 * i + 1] = q.y; c[4 * i + 2] = q.z; c[4 * i + 3] = q.w;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < ILP; i++) acc += v[i].x * c[2 * i] + v[i].y * c[2 * i + 1];
+  }
+  if (acc == 12345.678) out[0] = acc;
+}
+
+template <int T, int ILP, int W, bool PAIR32>
+static void run_two(const d2 *a, const int *b, size_t nvec, double *out, int cus, int bpc) {
+  const int blocks = cus * bpc;
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int w = 0; w < 2; w++) hipLaunchKernelGGL((k_two<T, ILP, W, PAIR32>), dim3(blocks), dim3(T), 0, 0, a, b, nvec, out);
+  CK(hipEventRecord(e0, 0));
+  for (int r = 0; r < 10; r++) hipLaunchKernelGGL((k_two<T, ILP, W, PAIR32>), dim3(blocks), dim3(T), 0, 0, a, b, nvec, out);
+  CK(hipEventRecord(e1, 0));
+  CK(hipEventSynchronize(e1));
+  float ms = 0;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  printf("two streams: T %4d bpc %d ilp %d, b in %2d-byte loads, a %s: %7.1f us  %5.2f TB/s\n", T, bpc, ILP, W, PAIR32 ? "in adjacent pairs (lane stride 32)" : "lane-consecutive",
+         ms * 100.0, (double)nvec * 24.0 / (ms * 1e-4) / 1e12);
+  fflush(stdout);
+}
+
 template <int T, int ILP, bool NT, int ORDER>
 static void run(const d2 *a, size_t nvec, double *out, int cus, int bpc) {
   const int blocks = cus * bpc;
@@ -78,5 +140,18 @@ int main() {
   run<256, 4, true, 2>(a, nvec, out, cus, 8);
   run<256, 2, true, 2>(a, nvec, out, cus, 8);
   run<256, 1, true, 0>(a, nvec, out, cus, 8);
+  int *bb;
+  CK(hipMalloc(&bb, nvec * 8));
+  CK(hipMemset(bb, 0, nvec * 8));
+  run_two<512, 4, 8, false>(a, bb, nvec, out, cus, 2);
+  run_two<512, 4, 16, false>(a, bb, nvec, out, cus, 2);
+  run_two<512, 4, 16, true>(a, bb, nvec, out, cus, 2);
+  run_two<512, 4, 8, true>(a, bb, nvec, out, cus, 2);
+  // ... and with both streams starting 40 / 20 bytes off a cache line, as a chunk of a CSR matrix does (the last tile is left out)
+  printf("misaligned by 40 / 20 bytes:\n");
+  run_two<512, 4, 8, false>(reinterpret_cast<const d2 *>(reinterpret_cast<const char *>(a) + 40), reinterpret_cast<const int *>(reinterpret_cast<const char *>(bb) + 20),
+                            nvec - (size_t)512 * 4 * 512, out, cus, 2);
+  run_two<256, 4, 8, false>(a, bb, nvec, out, cus, 8);
+  run_two<256, 4, 16, false>(a, bb, nvec, out, cus, 8);
   return 0;
 }
