@@ -133,7 +133,7 @@ __global__ void chunk_check_kernel(int nchunks, int ngroups, int R, int cap, int
 }
 
 static int group_max_cap() {   // value entries per chunk: 4088 = 32 KB of LDS, three blocks of 134 VGPRs per CU (MK_GROUP_MAX_CAP: up to 8184 for A/B runs)
-  static const int v = getenv("MK_GROUP_MAX_CAP") ? std::max(256, std::min(atoi(getenv("MK_GROUP_MAX_CAP")), 8184)) : 4088;
+  static const int v = getenv("MK_GROUP_MAX_CAP") ? std::max(256, std::min(atoi(getenv("MK_GROUP_MAX_CAP")), 8160)) : 4064;
   return v;
 }
 #define kGroupMaxCap group_max_cap()
@@ -227,11 +227,13 @@ __global__ __launch_bounds__(kGThreads) void spmv_group_kernel(
     double beta, double *__restrict__ slab, const int *__restrict__ done, int cap, int ccap) {
   if (done != nullptr && *done != 0) return;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  double *sval = reinterpret_cast<double *>(smem_raw);                     // cap + 2 doubles of stage, then a zero (below)
-  int *scol = reinterpret_cast<int *>(smem_raw + (size_t)(cap + 4) * 8);   // ccap + 8 ints
+  // (values and lists are staged from the last cache line boundary in front of the chunk's first value / list entry -- 16
+  // values, 32 columns --, so the stage holds up to 15 / 31 entries more than the chunk has; see spmv.hip kStreamAlignV)
+  double *sval = reinterpret_cast<double *>(smem_raw);                      // cap + 18 doubles of stage, then a zero (below)
+  int *scol = reinterpret_cast<int *>(smem_raw + (size_t)(cap + 20) * 8);   // ccap + 40 ints
   // Groups of EMPTY rows (and the lanes of a cut chunk that own no group) multiply nothing, but their lanes run the
   // multiply-adds of their wave with xv = 0: they must read a finite number, not whatever lies behind the staged span.
-  if (threadIdx.x == 0) sval[cap + 2] = 0.0;   // (visible after the first barrier of the loop; never overwritten by the stage)
+  if (threadIdx.x == 0) sval[cap + 18] = 0.0;   // (visible after the first barrier of the loop; never overwritten by the stage)
   constexpr int NV = 2 * U, NI = U;
   const int tid = threadIdx.x;
   const int g = tid % G, rl = tid / G;
@@ -247,7 +249,7 @@ __global__ __launch_bounds__(kGThreads) void spmv_group_kernel(
   // an LDS store costs one add and one compare.
   const unsigned toff = (unsigned)tid * 16u;
   auto stage_loads = [&](gi4_t cd) {   // cd: value span [x, y), list span [z, w)
-    const int vb_ = cd.x & ~1, ib_ = cd.z & ~3;
+    const int vb_ = cd.x & ~15, ib_ = cd.z & ~31;
     const char *vbase = reinterpret_cast<const char *>(val + vb_);
     const char *ibase = reinterpret_cast<const char *>(colc + ib_);
     const unsigned vbytes = (unsigned)(cd.y - vb_) * 8u, ibytes = (unsigned)(cd.w - ib_) * 4u;
@@ -277,7 +279,7 @@ __global__ __launch_bounds__(kGThreads) void spmv_group_kernel(
   }
   while (chunk < last) {
     const int cb = cd.x, ce = cd.y, ccb = cd.z, cce = cd.w;
-    const int vb = cb & ~1, ib = ccb & ~3;
+    const int vb = cb & ~15, ib = ccb & ~31;
     {
       const unsigned vbytes = (unsigned)(ce - vb) * 8u, ibytes = (unsigned)(cce - ib) * 4u;
       char *sv8 = reinterpret_cast<char *>(sval), *sc8 = reinterpret_cast<char *>(scol);
@@ -303,7 +305,7 @@ __global__ __launch_bounds__(kGThreads) void spmv_group_kernel(
     const gi4_t nnce2 = cdesc[2 * next2 + 1];
     const gi4_t ngd = gdesc[min(nce2.x + rl, ngroups)];
     __syncthreads();
-    const double *sv = (len > 0) ? sval + (cb - vb) + b0 : sval + cap + 2;   // sv[m * len + j]: value of list entry j in the group's m-th row
+    const double *sv = (len > 0) ? sval + (cb - vb) + b0 : sval + cap + 18;   // sv[m * len + j]: value of list entry j in the group's m-th row
     const int *sc = scol + cs;
     // The lane's first 8 list entries: all gathers issued before anything waits.  Slots no lane of the wave needs are skipped
     // by wave-uniform branches (an exec-masked slot would still take its issue cycles: with 78-entry lists on 16 lanes five
@@ -410,7 +412,7 @@ template <int MODE, int U, bool NT>
 static int launch_group_u(const mk_matrix *A, double alpha, const double *x, double beta, double *y, double *slab, const int *done, int *nblocks) {
   Context &c = ctx();
   const int G = A->group_lanes, cap = A->group_cap, ccap = A->group_ccap;
-  const size_t lds = (size_t)(cap + 4) * 8 + (size_t)(ccap + 8) * 4;
+  const size_t lds = (size_t)(cap + 20) * 8 + (size_t)(ccap + 40) * 4;
   const int nchunks = A->group_chunks;
   static const int env_bpc = getenv("MK_GROUP_BPC") ? atoi(getenv("MK_GROUP_BPC")) : 0;
   int per_cu = env_bpc > 0 ? env_bpc : A->group_bpc[MODE];
@@ -455,7 +457,7 @@ int launch_group(const mk_matrix *A, int mode, double alpha, const double *x, do
   const bool nt = nt_matrix((double)A->nnz * 8.0);
   const int cap = A->group_cap;
 #define MK_GROUP_PICK(UU)                                                                                      \
-  if (cap <= 1024 * UU - 8) {                                                                                  \
+  if (cap <= 1024 * UU - 32) {                                                                                 \
     if (mode == 0) return nt ? launch_group_u<0, UU, true>(A, alpha, x, beta, y, slab, done, nblocks)          \
                              : launch_group_u<0, UU, false>(A, alpha, x, beta, y, slab, done, nblocks);        \
     return nt ? launch_group_u<1, UU, true>(A, alpha, x, beta, y, slab, done, nblocks)                         \

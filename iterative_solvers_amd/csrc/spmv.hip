@@ -19,9 +19,14 @@
 namespace mk {
 
 constexpr int kThreads = 256;
-// LDS entries per block (12 B each, 48 KB at most -> three blocks per CU); MK_STREAM_MAX_CAP lowers it (3064: the limit until r02)
+// LDS entries per block (12 B each, 48 KB at most -> three blocks per CU); MK_STREAM_MAX_CAP lowers it (3064: the limit until r02).
+// A chunk is staged from the last cache line boundary in front of its first value / column (kStreamAlignV / kStreamAlignI
+// entries = 128 bytes), so the stage holds up to 15 values and 31 columns more than the chunk has: 4064 instead of 4088.
+// (Two streams read side by side run at 7.06 TB/s from aligned starts and at 5.41 TB/s from starts 40 / 20 bytes off a line:
+// tools/microbench/read_stream.hip.)
+constexpr int kStreamAlignV = 16, kStreamAlignI = 32;
 static int stream_max_cap() {
-  static const int v = getenv("MK_STREAM_MAX_CAP") ? std::max(64, std::min(atoi(getenv("MK_STREAM_MAX_CAP")), 4088)) : 4088;
+  static const int v = getenv("MK_STREAM_MAX_CAP") ? std::max(64, std::min(atoi(getenv("MK_STREAM_MAX_CAP")), 4064)) : 4064;
   return v;
 }
 #define kStreamMaxCap stream_max_cap()
@@ -791,7 +796,7 @@ __global__ __launch_bounds__(kThreads) void spmv_stream_kernel(
   if (done != nullptr && *done != 0) return;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   double *sval = reinterpret_cast<double *>(smem_raw);                     // cap + 2 doubles
-  int *scol = reinterpret_cast<int *>(smem_raw + (size_t)(cap + 2) * 8);   // cap + 8 ints, or the pattern table
+  int *scol = reinterpret_cast<int *>(smem_raw + (size_t)(cap + kStreamAlignV + 2) * 8);   // cap + 40 ints, or the pattern table
   constexpr int R = kThreads / G;
   constexpr int NV = 2 * U, NI = COMP ? 0 : U;
   if (COMP)
@@ -844,7 +849,7 @@ __global__ __launch_bounds__(kThreads) void spmv_stream_kernel(
     cce_ = cptr[r1_ - 1] + (ce_ - rowptr[r1_ - 1]);
   };
   auto stage_loads = [&](int cb_, int ce_, int ccb_, int cce_) {
-    const int vb_ = cb_ & ~1, ib_ = ccb_ & ~3;
+    const int vb_ = cb_ & ~(kStreamAlignV - 1), ib_ = ccb_ & ~(kStreamAlignI - 1);
 #pragma unroll
     for (int i = 0; i < NV; i++) {
       const int k = vb_ + (tid + i * kThreads) * 2;
@@ -866,7 +871,7 @@ __global__ __launch_bounds__(kThreads) void spmv_stream_kernel(
     stage_loads(cb, ce, ccb, cce);
   }
   while (chunk < last) {
-    const int vb = cb & ~1, ib = ccb & ~3;
+    const int vb = cb & ~(kStreamAlignV - 1), ib = ccb & ~(kStreamAlignI - 1);
 #pragma unroll
     for (int i = 0; i < NV; i++) {
       const int k = vb + (tid + i * kThreads) * 2;
@@ -998,7 +1003,7 @@ static int launch_stream_u(const mk_matrix *A, double alpha, const double *x, do
   const int *table = COMP ? (shapes ? A->stab : A->ptab) : (shared_cols ? A->cptr : nullptr);
   const int *colv = shared_cols ? A->colc : A->col;
   const int shape_ints = shapes ? A->stab_shape_ints : 0;
-  const size_t lds = (size_t)(cap + 2) * 8 + (COMP ? (size_t)tab_ints * 4 + 16 : (size_t)(cap + 8) * 4);  // cap is a multiple of 4
+  const size_t lds = (size_t)(cap + kStreamAlignV + 2) * 8 + (COMP ? (size_t)tab_ints * 4 + 16 : (size_t)(cap + kStreamAlignI + 8) * 4);  // cap is a multiple of 4
   const int64_t nchunks = (A->nrows + (kThreads / G) - 1) / (kThreads / G);
   // resident blocks per CU for this instantiation (registers + LDS), so the grid is one full wave of blocks
   static const int env_bpc = getenv("MK_STREAM_BPC") ? atoi(getenv("MK_STREAM_BPC")) : 0;
@@ -1057,7 +1062,7 @@ static int launch_stream(const mk_matrix *A, double alpha, const double *x, doub
   // values larger than the Infinity Cache are streamed non-temporally
   const bool nt = nt_matrix((double)A->nnz * 8.0);
 #define MK_STREAM_PICK(UU)                                                                                         \
-  if (cap <= 1024 * UU - 8) {                                                                                      \
+  if (cap <= 1024 * UU - 32) {                                                                                     \
     if (A->pat) return nt ? launch_stream_u<MODE, UU, true, true>(A, alpha, x, beta, y, slab, done, nblocks, rhs, extra)   \
                           : launch_stream_u<MODE, UU, true, false>(A, alpha, x, beta, y, slab, done, nblocks, rhs, extra); \
     return nt ? launch_stream_u<MODE, UU, false, true>(A, alpha, x, beta, y, slab, done, nblocks, rhs, extra)              \
