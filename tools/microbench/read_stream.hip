@@ -81,6 +81,118 @@ __global__ __launch_bounds__(T) void k_two(const d2 *__restrict__ a, const int *
   if (acc == 12345.678) out[0] = acc;
 }
 
+// ... and with the LDS traffic and the two barriers per step of the band kernel beside the streams: every step stores its
+// products in LDS (16 bytes per lane and load), barrier, every lane reads GATHER doubles back from scattered addresses, barrier.
+template <int T, int ILP, int GATHER>
+__global__ __launch_bounds__(T) void k_two_lds(const d2 *__restrict__ a, const int *__restrict__ b, size_t nvec, double *__restrict__ out) {
+  __shared__ d2 stage[T * ILP];
+  const size_t tile = (size_t)T * ILP;
+  const size_t per = nvec / tile / gridDim.x;
+  double acc = 0.0;
+  const double *sd = reinterpret_cast<const double *>(stage);
+  for (size_t s = 0; s < per; s++) {
+    const size_t t0 = ((size_t)blockIdx.x * per + s) * tile;
+    d2 v[ILP];
+    i2 c[ILP];
+#pragma unroll
+    for (int i = 0; i < ILP; i++) v[i] = __builtin_nontemporal_load(a + t0 + (size_t)i * T + threadIdx.x);
+#pragma unroll
+    for (int i = 0; i < ILP; i++) c[i] = __builtin_nontemporal_load(reinterpret_cast<const i2 *>(b) + t0 + (size_t)i * T + threadIdx.x);
+#pragma unroll
+    for (int i = 0; i < ILP; i++) {
+      d2 p;
+      p.x = v[i].x * c[i].x; p.y = v[i].y * c[i].y;
+      stage[i * T + threadIdx.x] = p;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < GATHER; g++) acc += sd[((threadIdx.x * 37u + g * 613u + (unsigned)s * 11u) % (unsigned)(2 * T * ILP))];
+    __syncthreads();
+  }
+  if (acc == 12345.678) out[0] = acc;
+}
+// ... and closer still to the band kernel: the LDS reads are GATHERS whose addresses come from the loaded columns (a ring of
+// M doubles), their products go to the stage, and behind the barrier G lanes per "row" of ROWLEN entries add them up, a
+// shuffle tree finishes the row, one lane per row stores y (nontemporal) -- fixed row length, everything else as in band.hip.
+template <int T, int ILP, int G, int MRING>
+__global__ __launch_bounds__(T) void k_band_like(const d2 *__restrict__ a, const int *__restrict__ b, size_t nvec, double *__restrict__ y, double *__restrict__ out) {
+  extern __shared__ double sm[];
+  double *xw = sm;                 // MRING doubles
+  double *stage = sm + MRING;      // 2 T ILP doubles
+  for (int i = threadIdx.x; i < MRING; i += T) xw[i] = 1.0;
+  __syncthreads();
+  const size_t tile = (size_t)T * ILP;
+  const size_t per = nvec / tile / gridDim.x;
+  constexpr int R = T / G;                       // rows per step
+  constexpr int ROWLEN = 2 * ILP * G;            // entries per row (all of the tile's 2 T ILP entries)
+  const int g = threadIdx.x % G, rl = threadIdx.x / G;
+  double acc = 0.0;
+  for (size_t s = 0; s < per; s++) {
+    const size_t t0 = ((size_t)blockIdx.x * per + s) * tile;
+    d2 v[ILP];
+    i2 c[ILP];
+#pragma unroll
+    for (int i = 0; i < ILP; i++) v[i] = __builtin_nontemporal_load(a + t0 + (size_t)i * T + threadIdx.x);
+#pragma unroll
+    for (int i = 0; i < ILP; i++) c[i] = __builtin_nontemporal_load(reinterpret_cast<const i2 *>(b) + t0 + (size_t)i * T + threadIdx.x);
+#pragma unroll
+    for (int i = 0; i < ILP; i++) {
+      const unsigned s0 = (unsigned)(c[i].x + (int)(threadIdx.x * 37u + i * 101u)) % (unsigned)MRING;
+      const unsigned s1 = (unsigned)(c[i].y + (int)(threadIdx.x * 53u + i * 211u)) % (unsigned)MRING;
+      d2 p;
+      p.x = v[i].x * xw[s0]; p.y = v[i].y * xw[s1];
+      reinterpret_cast<d2 *>(stage)[i * T + threadIdx.x] = p;
+    }
+    __syncthreads();
+    double sum = 0.0;
+#pragma unroll
+    for (int t = 0; t < 2 * ILP; t++) sum += stage[rl * ROWLEN + g + t * G];
+#pragma unroll
+    for (int off = G / 2; off > 0; off >>= 1) sum += __shfl_down(sum, off, G);
+    if (g == 0) __builtin_nontemporal_store(sum, y + ((size_t)blockIdx.x * per + s) * R + rl);
+    acc += sum;
+    __syncthreads();
+  }
+  if (acc == 12345.678) out[0] = acc;
+}
+template <int T, int ILP, int G, int MRING>
+static void run_band_like(const d2 *a, const int *b, size_t nvec, double *y, double *out, int cus, int bpc) {
+  const int blocks = cus * bpc;
+  const size_t lds = ((size_t)MRING + 2 * T * ILP) * 8;
+  auto kern = k_band_like<T, ILP, G, MRING>;
+  CK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int w = 0; w < 2; w++) hipLaunchKernelGGL(kern, dim3(blocks), dim3(T), lds, 0, a, b, nvec, y, out);
+  CK(hipEventRecord(e0, 0));
+  for (int r = 0; r < 10; r++) hipLaunchKernelGGL(kern, dim3(blocks), dim3(T), lds, 0, a, b, nvec, y, out);
+  CK(hipEventRecord(e1, 0));
+  CK(hipEventSynchronize(e1));
+  CK(hipGetLastError());
+  float ms = 0;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  printf("band-like (ring gathers by loaded columns, stage, row pass with %d lanes per row, y stored): T %4d bpc %d ilp %d ring %d: %7.1f us  %5.2f TB/s\n", G, T, bpc, ILP, MRING,
+         ms * 100.0, (double)nvec * 24.0 / (ms * 1e-4) / 1e12);
+  fflush(stdout);
+}
+
+template <int T, int ILP, int GATHER>
+static void run_two_lds(const d2 *a, const int *b, size_t nvec, double *out, int cus, int bpc) {
+  const int blocks = cus * bpc;
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int w = 0; w < 2; w++) hipLaunchKernelGGL((k_two_lds<T, ILP, GATHER>), dim3(blocks), dim3(T), 0, 0, a, b, nvec, out);
+  CK(hipEventRecord(e0, 0));
+  for (int r = 0; r < 10; r++) hipLaunchKernelGGL((k_two_lds<T, ILP, GATHER>), dim3(blocks), dim3(T), 0, 0, a, b, nvec, out);
+  CK(hipEventRecord(e1, 0));
+  CK(hipEventSynchronize(e1));
+  float ms = 0;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  printf("two streams + LDS stage + 2 barriers per step: T %4d bpc %d ilp %d, %d scattered LDS reads per lane: %7.1f us  %5.2f TB/s\n", T, bpc, ILP, GATHER,
+         ms * 100.0, (double)nvec * 24.0 / (ms * 1e-4) / 1e12);
+  fflush(stdout);
+}
+
 template <int T, int ILP, int W, bool PAIR32>
 static void run_two(const d2 *a, const int *b, size_t nvec, double *out, int cus, int bpc) {
   const int blocks = cus * bpc;
@@ -147,6 +259,15 @@ int main() {
   run_two<512, 4, 16, false>(a, bb, nvec, out, cus, 2);
   run_two<512, 4, 16, true>(a, bb, nvec, out, cus, 2);
   run_two<512, 4, 8, true>(a, bb, nvec, out, cus, 2);
+  run_two_lds<512, 4, 0>(a, bb, nvec, out, cus, 2);
+  run_two_lds<512, 4, 8>(a, bb, nvec, out, cus, 2);
+  run_two_lds<512, 4, 16>(a, bb, nvec, out, cus, 2);
+  run_two_lds<256, 4, 8>(a, bb, nvec, out, cus, 4);
+  double *yy;
+  CK(hipMalloc(&yy, nvec / 4 * 8 + 4096));
+  run_band_like<512, 4, 8, 6072>(a, bb, nvec, yy, out, cus, 2);
+  run_band_like<512, 3, 8, 6072>(a, bb, nvec, yy, out, cus, 2);
+  run_band_like<512, 2, 8, 6072>(a, bb, nvec, yy, out, cus, 2);
   // ... and with both streams starting 40 / 20 bytes off a cache line, as a chunk of a CSR matrix does (the last tile is left out)
   printf("misaligned by 40 / 20 bytes:\n");
   run_two<512, 4, 8, false>(reinterpret_cast<const d2 *>(reinterpret_cast<const char *>(a) + 40), reinterpret_cast<const int *>(reinterpret_cast<const char *>(bb) + 20),
