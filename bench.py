@@ -625,7 +625,7 @@ def main():
                               "spmv_ms": round(ms4, 4), "spmv_frac": round(b4 / (ms4 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                               "spmv_bytes_model": "SURVEY 8(d): 12 nnz + 20 n + 4", "spmv_kernel": KERNEL_NAMES.get(i4.kernel),
                               "index_patterns": i4.index_patterns, "shared_column_entries": i4.shared_columns,
-                              "row_groups": i4.row_groups, "group_lanes": i4.group_lanes, "band_window": i4.band_window,
+                              "row_groups": i4.row_groups, "group_lanes": i4.group_lanes, "band_window": i4.band_window, "band_strips": i4.band_strips,
                               "stream_lanes": i4.stream_lanes, "stream_chunk": i4.stream_chunk}
                 del A4, x4, y4, vals
         except Exception as e:      # never lose the headline to a secondary measurement

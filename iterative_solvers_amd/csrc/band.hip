@@ -285,6 +285,10 @@ static int build_strips(mk_matrix *A, int64_t need) {
   // worth it while a strip keeps about six entries per row (below that y and the row pointers outweigh the entries)
   const double min_per_row = getenv("MK_BAND_STRIP_MIN_LEN") ? atof(getenv("MK_BAND_STRIP_MIN_LEN")) : 6.0;
   if (S < 2 || S > kMaxStrips || A->info.mean_row_len < min_per_row * S) return MK_OK;
+  // ... and while a strip's launch keeps every block busy for a few chunks: on 400 000 rows of 80 entries the eight launches of
+  // three chunks per block each (0.28 of the roofline) lose to the stream kernel's one (0.34)
+  const int64_t strip_min_rows = getenv("MK_BAND_STRIP_MIN_ROWS") ? atoll(getenv("MK_BAND_STRIP_MIN_ROWS")) : 750000;
+  if (A->nrows < strip_min_rows) return MK_OK;
   const int wd = (int)(((span + S - 1) / S + 7) & ~(int64_t)7);
   (void)need;
   uint32_t *counts = nullptr, *d_total = nullptr;

@@ -1047,7 +1047,7 @@ def test_spmv_band_kernel_diagonal_strips(seed, n, mean, hw, empty):
     oracle on the CSR as given, 1e-12 per row (the row's sum is formed strip by strip: another order, still a fixed one)."""
     rng = np.random.default_rng(seed)
     rp, ci, v = _banded_matrix(rng, n, mean, hw, empty)
-    with _env(MK_BAND_MIN_ROWS=1000):
+    with _env(MK_BAND_MIN_ROWS=1000, MK_BAND_STRIP_MIN_ROWS=1000):   # (strips are for matrices of 750 000 rows and more by default)
         A = mk.Matrix.from_csr(n, n, rp, ci, v)
         i = A.info()
     assert i.kernel == mk.SPMV_STREAM and i.band_strips >= 2 and 0 < i.band_window < 8000, (i.band_strips, i.band_window)
@@ -1067,7 +1067,7 @@ def test_spmv_band_kernel_diagonal_strips(seed, n, mean, hw, empty):
     y1 = y.get().copy()
     A.spmv_dot(x, y)
     assert _same_bits(y.get(), y1)                     # the same bits from run to run
-    with _env(MK_BAND_MIN_ROWS=1000, MK_NO_BAND_STRIPS=1):     # without strips: one window with one block per CU where that fits, else the stream kernel
+    with _env(MK_BAND_MIN_ROWS=1000):     # below the strips' size threshold (or with MK_NO_BAND_STRIPS=1): one window with one block per CU where that fits, else the stream kernel
         B = mk.Matrix.from_csr(n, n, rp, ci, v)
         ib = B.info()
         assert ib.band_strips == 0 and (ib.band_window == 0 or ib.band_window > 2 * hw)
