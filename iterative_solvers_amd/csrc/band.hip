@@ -351,7 +351,7 @@ int build_band_plan(mk_matrix *A) {
   int64_t need = 0;
   MK_TRY(plan_band(A, &need, env_lds ? env_lds : kBandLdsTwo));
   if (!A->band_desc && need > 0) MK_TRY(build_strips(A, need));
-  if (!A->band_desc && !A->nstrips && need > 0 && !env_lds) MK_TRY(plan_band(A, nullptr, kBandLdsOne));
+  if (!A->band_desc && !A->nstrips && need > 0 && !env_lds && (need + 1024) * 8 <= kBandLdsOne) MK_TRY(plan_band(A, nullptr, kBandLdsOne));   // (not worth the second pass over the row pointers when the window alone is too large)
   return MK_OK;
 }
 
