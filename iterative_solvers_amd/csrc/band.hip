@@ -15,8 +15,9 @@
 //            strips (build_strips below), each with a plan of its own; last resort: one window, one block per CU;
 //   pass 1 reads the chunk's (value, column) pairs with coalesced 16- and 8-byte loads requested ahead of their use
 //            (two register sets; measured: how far ahead does not matter), multiplies every value with its x
-//            from the ring and leaves the products in LDS; pass 2 gives every row G lanes that add the row's products (lane g: entries g, g + G, ..., then a
-//            shuffle tree: the stream kernel's order for the same G).
+//            from the ring and leaves the products in LDS;
+//   pass 2 gives every row G lanes that add the row's products (lane g: entries g, g + G, ..., then a shuffle tree: the
+//            stream kernel's order for the same G).
 // No gather leaves the CU; x is read once per block.  HBM bytes: 12 per entry + 20 per row + 16 per chunk of descriptors.
 // Results agree with the serial reference to 1e-12 (tests), and are the same from run to run (no atomics, fixed order).
 // Algorithmic bytes: SURVEY 8(d)'s 12 nnz + 20 n + 4.
@@ -125,8 +126,7 @@ static int plan_band(mk_matrix *A, int64_t *need_out, int lds_budget) {
   const int cap = ((fullest + 3) & ~3) + kBandAlign;   // (the stage holds the entries in front of the chunk, back to the aligned start, as well)
   const int64_t M = (need + 7) & ~(int64_t)7;
   const int64_t lds = (M + cap + 4) * 8;
-  // the window must fit beside the product stage; a window of more than 64 entries per row of the chunk is a matrix whose
-  // rows are not near each other's columns at all (every block would load most of x)
+  // the window must fit beside the product stage (a window as long as x itself is not a window)
   if (lds > lds_budget || M > (int64_t)A->ncols + 8) return MK_OK;
   const int per_cu = lds <= 80 * 1024 ? 2 : 1;
   int nb = (int)std::min<int64_t>(((int64_t)nchunks + 7) / 8 * 8, (int64_t)c.num_cus * per_cu);

@@ -649,6 +649,21 @@ int analyse_matrix(mk_matrix *A) {
   // regular rows -> stream; rows too long for a row-aligned LDS chunk (skewed / power law) -> split
   const bool was_auto = (A->kernel == MK_SPMV_AUTO);
   if (A->kernel == MK_SPMV_AUTO) A->kernel = stream_ok ? MK_SPMV_STREAM : MK_SPMV_SPLIT;
+  // A few fat rows among regular ones (constraint rows of a finite-element matrix) fail the stream kernel's test on the longest
+  // row, but not the band kernel's needs: its chunks are packed by entries, a fat row takes a chunk (nearly) of its own and
+  // costs that chunk a longer row pass, nothing else.  Where such rows are rare (one row in a thousand beyond the stream
+  // kernel's limit) and the band plan exists, the band kernel serves the matrix instead of the split kernel (the stream kernel
+  // stays behind it for the Jacobi sweep).
+  if (was_auto && A->kernel == MK_SPMV_SPLIT && stream_fits && sl <= 4 * sl_mean && I.mean_row_len >= 16.0) {
+    int64_t fat = 0;
+    for (int k = 0; k < 16; k++)
+      if ((k == 0 ? 0 : (1 << (k - 1))) > 32 * sl) fat += I.hist[k];   // (buckets wholly beyond the limit; the one that straddles it is not counted)
+    static const int no_rescue = getenv("MK_NO_BAND_FAT_ROWS") ? atoi(getenv("MK_NO_BAND_FAT_ROWS")) : 0;
+    if (!no_rescue && fat * 1000 <= A->nrows && I.max_row_len <= 2048) {
+      MK_TRY(build_band_plan(A));
+      if (A->band_desc || A->nstrips) A->kernel = MK_SPMV_STREAM;
+    }
+  }
   if (A->kernel == MK_SPMV_STREAM && !stream_fits) A->kernel = MK_SPMV_SPLIT;
   int64_t longr = 0;
   for (int k = 12; k < 16; k++) longr += I.hist[k];   // rows of 2048 entries or more always cross a chunk border
@@ -658,7 +673,7 @@ int analyse_matrix(mk_matrix *A) {
   I.kernel = A->kernel;
   I.lanes_per_row = A->lanes;
   I.index_patterns = 0;
-  if (A->kernel == MK_SPMV_STREAM) {
+  if (A->kernel == MK_SPMV_STREAM && !(A->band_desc || A->nstrips)) {
     MK_TRY(try_compress<true>(A));                 // offsets and values shared by rows -> pattern kernel
     if (!A->pat) MK_TRY(try_compress<false>(A));   // offsets only -> stream kernel without col[]
     if (!A->pat) MK_TRY(try_share_columns(A));     // rows repeating their neighbour's column list -> lists stored once

@@ -1076,6 +1076,46 @@ def test_spmv_band_kernel_diagonal_strips(seed, n, mean, hw, empty):
     assert (np.abs(y2.get() - y1) / np.maximum(mag, 1e-300)).max() <= SPMV_RTOL
 
 
+def test_spmv_band_kernel_serves_rare_fat_rows():
+    """a few fat rows (constraint rows) among regular ones fail the stream kernel's test on the longest row; the band kernel packs
+    its chunks by entries and serves the matrix instead of the split kernel; with more than one fat row in a thousand the split
+    kernel keeps it"""
+    rng = np.random.default_rng(31)
+    n = 40000
+    lens = rng.integers(30, 61, n)
+    fat = rng.choice(n, 30, replace=False)
+    lens[fat] = rng.integers(600, 1400, 30)
+    rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    rows = np.repeat(np.arange(n), lens)
+    ci = np.clip(rows + rng.integers(-1500, 1501, rows.size), 0, n - 1)
+    ci = ci[np.lexsort((ci, rows))].astype(np.int32)
+    v = rng.normal(size=ci.size)
+    with _env(MK_BAND_MIN_ROWS=1000):
+        A = mk.Matrix.from_csr(n, n, rp, ci, v)
+        i = A.info()
+    assert i.kernel == mk.SPMV_STREAM and i.band_window > 0 and i.max_row_len >= 600, (i.kernel, i.band_window, i.max_row_len)
+    _check_spmv(A, rp, ci, v, n, n, rng)
+    _check_spmv(A, rp, ci, v, n, n, rng, alpha=-1.5, beta=0.5)
+    xh = rng.normal(size=n)
+    x, y = mk.Vector(n, values=xh), mk.Vector(n, fill=5.0)
+    yx, xx = A.spmv_dot(x, y)
+    ref = oracle.csr_spmv(rp, ci, v, xh)
+    mag = oracle.csr_spmv(rp, ci, np.abs(v), np.abs(xh))
+    assert (np.abs(y.get() - ref) / np.maximum(mag, 1e-300)).max() <= SPMV_RTOL
+    assert abs(yx - ref @ xh) <= 1e-12 * np.abs(ref * xh).sum()
+    # a Jacobi sweep on it takes the stream kernel behind the band plan (the diagonal is not stored in every row: values only)
+    lens[rng.choice(n, 400, replace=False)] = 700          # one fat row in a hundred: the split kernel's
+    rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    rows = np.repeat(np.arange(n), lens)
+    ci = np.clip(rows + rng.integers(-1500, 1501, rows.size), 0, n - 1)
+    ci = ci[np.lexsort((ci, rows))].astype(np.int32)
+    v = rng.normal(size=ci.size)
+    with _env(MK_BAND_MIN_ROWS=1000):
+        B = mk.Matrix.from_csr(n, n, rp, ci, v)
+        assert B.info().kernel == mk.SPMV_SPLIT and B.info().band_window == 0
+    _check_spmv(B, rp, ci, v, n, n, rng)
+
+
 def test_spmv_band_kernel_one_block_per_cu_window():
     """a window beyond half a CU's LDS on rows too short for strips (fewer than six entries per row and strip): one window, one
     block per CU"""

@@ -48,6 +48,19 @@ def rand(n, mean, hw):
     return n, rp.astype(np.int32), ci
 
 
+def randfat(n, mean, hw, every, fat):
+    """`rand` with one row of `fat` entries every `every` rows (constraint rows among regular ones)"""
+    rng = np.random.default_rng(4)
+    lens = rng.integers(mean * 2 // 3, mean * 4 // 3 + 1, n)
+    lens[every // 2::every] = fat
+    rp = np.concatenate([[0], np.cumsum(lens)])
+    nnz = int(rp[-1])
+    rows = np.repeat(np.arange(n), lens)
+    ci = np.clip(rows + rng.integers(-hw, hw + 1, nnz), 0, n - 1).astype(np.int32)
+    ci = ci[np.lexsort((ci, rows))]
+    return n, rp.astype(np.int32), ci
+
+
 def rand3(nodes, mean_nb, hw):
     """3 unknowns per node; every node couples to itself and ~mean_nb random nodes within +-hw, as full 3x3 blocks: the three
     rows of a node share their column list, no two nodes share a pattern"""
@@ -142,6 +155,8 @@ def main():
             run(f"skew {args[1]} {args[2]} {args[3]} {args[4]}", *skew(*(int(a) for a in args[1:5]))); args = args[5:]
         elif args[0] == "rand3":
             run(f"rand3 {args[1]} {args[2]} {args[3]}", *rand3(int(args[1]), int(args[2]), int(args[3]))); args = args[4:]
+        elif args[0] == "randfat":
+            run(f"randfat {' '.join(args[1:6])}", *randfat(*(int(a) for a in args[1:6]))); args = args[6:]
         elif args[0] == "hex3":
             run(f"hex3 {args[1]}", *hex3(int(args[1]))); args = args[2:]
         else:
