@@ -654,7 +654,7 @@ int analyse_matrix(mk_matrix *A) {
   // costs that chunk a longer row pass, nothing else.  Where such rows are rare (one row in a thousand beyond the stream
   // kernel's limit) and the band plan exists, the band kernel serves the matrix instead of the split kernel (the stream kernel
   // stays behind it for the Jacobi sweep).
-  if (was_auto && A->kernel == MK_SPMV_SPLIT && stream_fits && sl <= 4 * sl_mean && I.mean_row_len >= 16.0) {
+  if (was_auto && A->kernel == MK_SPMV_SPLIT && stream_fits && sl <= 4 * sl_mean) {
     int64_t fat = 0;
     for (int k = 0; k < 16; k++)
       if ((k == 0 ? 0 : (1 << (k - 1))) > 32 * sl) fat += I.hist[k];   // (buckets wholly beyond the limit; the one that straddles it is not counted)

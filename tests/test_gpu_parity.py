@@ -1121,7 +1121,7 @@ def test_spmv_band_kernel_one_block_per_cu_window():
     block per CU"""
     rng = np.random.default_rng(21)
     n = 60000
-    rp, ci, v = _banded_matrix(rng, n, 17, 6000)   # (about 16.5 entries per row: above the kernel's threshold of 16, below 3 strips x 6)
+    rp, ci, v = _banded_matrix(rng, n, 17, 6000)   # (about 16.5 entries per row: below 3 strips x 6)
     with _env(MK_BAND_MIN_ROWS=1000):
         A = mk.Matrix.from_csr(n, n, rp, ci, v)
         i = A.info()
@@ -1131,7 +1131,7 @@ def test_spmv_band_kernel_one_block_per_cu_window():
 
 
 def test_spmv_band_kernel_declines_wide_rows_and_small_matrices():
-    """no plan when the window of a panel would not fit the LDS budget, when rows are short, or below the size threshold"""
+    """no plan when the window would not fit the LDS, when rows are shorter than asked for, or below the size threshold"""
     rng = np.random.default_rng(7)
     rp, ci, v = _banded_matrix(rng, 40000, 30, 18000)
     with _env(MK_BAND_MIN_ROWS=1000):
@@ -1139,12 +1139,12 @@ def test_spmv_band_kernel_declines_wide_rows_and_small_matrices():
         assert A.info().band_window == 0
     _check_spmv(A, rp, ci, v, 40000, 40000, rng)
     rp, ci, v = _banded_matrix(rng, 30000, 9, 300)
+    with _env(MK_BAND_MIN_ROWS=1000, MK_BAND_MIN_LEN=16):
+        A = mk.Matrix.from_csr(30000, 30000, rp, ci, v)
+        assert A.info().band_window == 0          # mean row length below the threshold asked for
     with _env(MK_BAND_MIN_ROWS=1000):
         A = mk.Matrix.from_csr(30000, 30000, rp, ci, v)
-        assert A.info().band_window == 0          # mean row length below 16
-    with _env(MK_BAND_MIN_ROWS=1000, MK_BAND_MIN_LEN=4):
-        A = mk.Matrix.from_csr(30000, 30000, rp, ci, v)
-        assert A.info().band_window > 0
+        assert A.info().band_window > 0           # (default: from four entries per row on)
     _check_spmv(A, rp, ci, v, 30000, 30000, rng)
     rp, ci, v = _banded_matrix(rng, 30000, 30, 300)
     A = mk.Matrix.from_csr(30000, 30000, rp, ci, v)

@@ -11,7 +11,7 @@ import iterative_solvers_amd as mk
 def case(rng, k):
     n = int(rng.integers(20000, 400000))
     extra_cols = int(rng.choice([0, 0, 0, 1, 777]))
-    mean = int(rng.integers(16, 110))
+    mean = int(rng.choice([int(rng.integers(4, 16)), int(rng.integers(16, 110))]))
     hw = int(rng.choice([50, 400, 1500, 3000, 5000, 9000, 20000]))
     lens = rng.integers(max(1, mean // 3), mean * 5 // 3 + 1, n)
     if rng.random() < 0.5:                       # empty stretches
