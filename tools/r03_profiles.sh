@@ -25,7 +25,7 @@ timeout -k 10 200 python3 $R/tools/dist_probe.py 512 512 512 8 100 > $O/r03_dist
 timeout -k 10 300 rocprofv3 --kernel-trace -d $O/r03_dist_prof -o dist --output-format csv -- python3 $R/tools/dist_probe.py 512 512 512 8 40 > $O/r03_dist_probe.txt 2>&1 || exit 1
 unset MK_PROBE_SINGLE
 # (5) FE-like matrices, (6) 27-point variable coefficients on the long-row vsweep kernel: time and HBM traffic
-timeout -k 10 400 python3 $R/tools/fem_probe.py hex3 64 hex3 100 nine 3000 rand3 700000 15 300 rand3 500000 26 300 rand3 500000 26 30 rand 2000000 45 3000 rand 3000000 24 1500 rand 2000000 45 7000 rand 1500000 80 20000 randfat 2000000 45 3000 2000 1000 > $O/r03_fem_like_matrices.txt 2>&1 || exit 1
+timeout -k 10 700 python3 $R/tools/fem_probe.py hex3 64 hex3 100 nine 3000 rand3 700000 15 300 rand3 500000 26 300 rand3 500000 26 30 rand 2000000 45 3000 rand 3000000 24 1500 rand 2000000 45 7000 rand 1500000 80 20000 randfat 2000000 45 3000 2000 1000 rand 6000000 7 1000 > $O/r03_fem_like_matrices.txt 2>&1 || exit 1
 export MK_PROBE_KIND=27
 timeout -k 10 200 python3 $R/tools/vsweep_probe.py 256x256x256 512x512x64 > $O/r03_vsweep27_probe.txt 2>&1 || exit 1
 timeout -k 10 200 python3 $R/tools/vcg_probe.py 0 256,256,256 512,512,64 >> $O/r03_vsweep27_probe.txt 2>&1 || exit 1
