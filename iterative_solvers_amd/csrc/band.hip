@@ -264,6 +264,8 @@ static void free_strips(mk_matrix *A) {
   A->nstrips = 0;
 }
 
+static int try_strips(mk_matrix *A, int S, int dmin, int64_t span, int *ok);
+
 static int build_strips(mk_matrix *A, int64_t need) {
   const int off = getenv("MK_NO_BAND_STRIPS") ? atoi(getenv("MK_NO_BAND_STRIPS")) : 0;
   if (off || A->nstrips) return MK_OK;
@@ -278,19 +280,47 @@ static int build_strips(mk_matrix *A, int64_t need) {
   dev_free(range);
   if (h_range[1] < h_range[0]) return MK_OK;
   const int64_t span = (int64_t)h_range[1] - h_range[0] + 1;
-  // strip width: the window of a strip is its width + the rows of a chunk (256 with one or two lanes per row); two blocks per
-  // CU leave 80 KB - the stage, i.e. about 6000 doubles
-  const int wd_max = getenv("MK_BAND_STRIP_WIDTH") ? std::max(64, atoi(getenv("MK_BAND_STRIP_WIDTH"))) : 5400;
-  const int S = (int)((span + wd_max - 1) / wd_max);
-  // worth it while a strip keeps about six entries per row (below that y and the row pointers outweigh the entries)
+  (void)need;
+  // worth it while a strip keeps about six entries per row (below that y and the row pointers outweigh the entries) ...
   const double min_per_row = getenv("MK_BAND_STRIP_MIN_LEN") ? atof(getenv("MK_BAND_STRIP_MIN_LEN")) : 6.0;
-  if (S < 2 || S > kMaxStrips || A->info.mean_row_len < min_per_row * S) return MK_OK;
   // ... and while a strip's launch keeps every block busy for a few chunks: on 400 000 rows of 80 entries the eight launches of
   // three chunks per block each (0.28 of the roofline) lose to the stream kernel's one (0.34)
   const int64_t strip_min_rows = getenv("MK_BAND_STRIP_MIN_ROWS") ? atoll(getenv("MK_BAND_STRIP_MIN_ROWS")) : 750000;
   if (A->nrows < strip_min_rows) return MK_OK;
+  // The fewest strips whose windows fit: a strip's window is its width + the rows of a chunk, and two blocks per CU leave it
+  // 80 KB less the product stage, which shrinks with the strip's rows (MK_BAND_STRIP_WIDTH fixes the width instead).  The
+  // estimate is checked by planning: a strip that does not get its plan sends the loop on to one strip more.
+  int S0 = 2;
+  if (getenv("MK_BAND_STRIP_WIDTH")) {
+    const int wd_env = std::max(64, atoi(getenv("MK_BAND_STRIP_WIDTH")));
+    S0 = (int)std::max<int64_t>(2, (span + wd_env - 1) / wd_env);
+  } else {
+    for (; S0 <= kMaxStrips; S0++) {
+      const double mean_s = A->info.mean_row_len / S0;
+      int sl = 1;
+      while (sl < 32 && (double)sl * 16.0 < mean_s) sl *= 2;
+      const int Rs = kBThreads / (2 * sl);
+      const int64_t cap_est = std::min<int64_t>(4080, (int64_t)(1.25 * Rs * mean_s) + 64 + kBandAlign + 32);
+      const int64_t m_max = kBandLdsTwo / 8 - cap_est - 16;
+      if ((span + S0 - 1) / S0 + Rs + 72 <= m_max) break;
+    }
+  }
+  for (int S = S0; S <= kMaxStrips && S <= S0 + 2; S++) {
+    if (A->info.mean_row_len < min_per_row * S) return MK_OK;
+    int ok = 0;
+    MK_TRY(try_strips(A, S, h_range[0], span, &ok));
+    if (ok) return MK_OK;
+  }
+  return MK_OK;
+}
+
+// cut into S strips and plan each; *ok = 1 when every strip has its plan (else nothing is left behind)
+static int try_strips(mk_matrix *A, int S, int dmin, int64_t span, int *ok) {
+  *ok = 0;
+  Context &c = ctx();
+  const int blocks = (int)std::min<int64_t>((A->nrows + 255) / 256, 4096);
+  const int h_range[1] = {dmin};
   const int wd = (int)(((span + S - 1) / S + 7) & ~(int64_t)7);
-  (void)need;
   uint32_t *counts = nullptr, *d_total = nullptr;
   if (dev_alloc(&counts, (size_t)S * A->nrows) != MK_OK) return MK_OK;
   if (dev_alloc(&d_total, 1) != MK_OK) { dev_free(counts); return MK_OK; }
@@ -335,6 +365,7 @@ static int build_strips(mk_matrix *A, int64_t need) {
               T->band_lanes, T->band_cap, T->band_window, T->band_blocks, T->band_chunks);
   }
   A->band_window = wmax;
+  *ok = 1;
   return MK_OK;
 }
 

@@ -1051,7 +1051,7 @@ def test_spmv_band_kernel_diagonal_strips(seed, n, mean, hw, empty):
         A = mk.Matrix.from_csr(n, n, rp, ci, v)
         i = A.info()
     assert i.kernel == mk.SPMV_STREAM and i.band_strips >= 2 and 0 < i.band_window < 8000, (i.band_strips, i.band_window)
-    assert i.band_strips == -(-(2 * hw + 3) // 5400) or i.band_strips == -(-(2 * hw + 1) // 5400), i.band_strips
+    assert -(-(2 * hw) // 7000) <= i.band_strips <= -(-(2 * hw + 3) // 5400), i.band_strips   # (the fewest strips whose windows fit beside the stage)
     _check_spmv(A, rp, ci, v, n, n, rng)
     _check_spmv(A, rp, ci, v, n, n, rng, alpha=-0.75, beta=1.25)
     _check_spmv(A, rp, ci, v, n, n, rng, alpha=2.0, beta=-1.0)
