@@ -117,6 +117,55 @@ def test_dist_node_block_matrix_spmv_and_pcg(world):
     assert np.linalg.norm(xg - o["x"]) <= 1e-7 * np.linalg.norm(o["x"])
 
 
+def test_dist_banded_matrix_through_the_band_kernel():
+    """a banded symmetric positive definite matrix without shared offsets or column lists over three row blocks: the diag
+    blocks take the band kernel (sliding window of x in LDS, band.hip) with the distributed vector's owned part as x; product
+    and CG against the global oracle"""
+    rng = np.random.default_rng(77)
+    n = 36000
+    r = np.repeat(np.arange(n), 10)
+    off = rng.integers(-700, 701, r.size)
+    c = np.where((r + off < 0) | (r + off >= n), r - off, r + off)
+    pairs = np.unique(np.concatenate([np.stack([r, c], 1), np.stack([c, r], 1), np.stack([np.arange(n)] * 2, 1)]), axis=0)
+    r, c = pairs[:, 0], pairs[:, 1]
+    key = np.minimum(r, c) * n + np.maximum(r, c)
+    _, inv = np.unique(key, return_inverse=True)
+    w = rng.uniform(-1.0, 1.0, inv.max() + 1)[inv]
+    absum = np.bincount(r, weights=np.abs(w), minlength=n)
+    w[r == c] = 1.2 * absum[r[r == c]] + 1.0
+    rp = np.concatenate([[0], np.cumsum(np.bincount(r, minlength=n))]).astype(np.int32)
+    ci = c.astype(np.int32)
+    world = 3
+    rs = mk.partition_rows(rp, world)
+    old = os.environ.get("MK_BAND_MIN_ROWS")
+    os.environ["MK_BAND_MIN_ROWS"] = "1000"
+    try:
+        As = _blocks(rp, ci, w, n, rs, mkd.Comm.local_world(world))
+        xh = rng.normal(size=n)
+        xs = [A.vector(values=xh[rs[k]:rs[k + 1]]) for k, A in enumerate(As)]
+        ys = [A.vector() for A in As]
+        mkd.dist_spmv(As, xs, ys)
+        assert all(A.diag_info().band_window > 0 for A in As), [A.diag_info().band_window for A in As]
+    finally:
+        if old is None:
+            del os.environ["MK_BAND_MIN_ROWS"]
+        else:
+            os.environ["MK_BAND_MIN_ROWS"] = old
+    got = np.concatenate([y.get() for y in ys])
+    ref = oracle.csr_spmv(rp, ci, w, xh)
+    mag = oracle.csr_spmv(rp, ci, np.abs(w), np.abs(xh))
+    assert (np.abs(got - ref) / np.maximum(mag, 1e-300)).max() <= 1e-12
+    bh = rng.normal(size=n)
+    o = oracle.pcg(rp, ci, w, bh, tol=1e-10, precond=1, maxit=500, want_norms=True)
+    bs = [A.vector(values=bh[rs[k]:rs[k + 1]]) for k, A in enumerate(As)]
+    x0 = [A.vector(fill=0.0) for A in As]
+    Ss = [mk.PCG(max_iter=500, tol=1e-10, precond=1, logging=1) for _ in As]
+    res = mkd.dist_pcg_solve(Ss, As, bs, x0)
+    assert res[0]["converged"] == 1 and abs(res[0]["iterations"] - o["iterations"]) <= 2
+    xg = np.concatenate([x.get() for x in x0])
+    assert np.linalg.norm(xg - o["x"]) <= 1e-8 * np.linalg.norm(o["x"])
+
+
 @pytest.mark.parametrize("world,precond", [(1, 0), (2, 1), (4, 0), (8, 1)])
 def test_dist_pcg_matches_oracle(world, precond):
     rp, ci, v = oracle.stencil_csr(7, 16, 16, 24)
