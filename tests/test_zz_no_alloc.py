@@ -1,6 +1,8 @@
 """mk_spmv_dot_static (the entry point that allocates nothing: all scratch in a file-scope device array) against
 mk_spmv_dot through the C ABI: y and both dot products bit for bit, on two calls in a row with the second input smaller
 than the first (the array keeps the previous call's contents), for every kernel family."""
+import os
+
 import numpy as np
 import pytest
 
@@ -33,6 +35,27 @@ def _matrix(case, size):
     elif case == "vsweep":
         A = mk.Matrix.stencil(7, *((64, 48, 36) if size else (32, 16, 10)), scale_seed=7)
         A.set_spmv_kernel(mk.SPMV_VSWEEP)
+    elif case in ("band", "strips"):
+        # rows near the diagonal that share nothing: the band kernel (sliding window of x in LDS), in one window or over
+        # diagonal strips (several launches, the dots in the last one)
+        n, mean, hw = ((60000, 80, 12000) if size else (40000, 72, 9000)) if case == "strips" else ((40000, 30, 800) if size else (12000, 20, 300))
+        lens = rng.integers(mean * 2 // 3, mean * 4 // 3 + 1, n)
+        rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        rows = np.repeat(np.arange(n), lens)
+        ci = np.clip(rows + rng.integers(-hw, hw + 1, rows.size), 0, n - 1)
+        ci = ci[np.lexsort((ci, rows))].astype(np.int32)
+        old = {k: os.environ.get(k) for k in ("MK_BAND_MIN_ROWS", "MK_BAND_STRIP_MIN_ROWS")}
+        os.environ.update({"MK_BAND_MIN_ROWS": "1000", "MK_BAND_STRIP_MIN_ROWS": "1000"})
+        try:
+            A = mk.Matrix.from_csr(n, n, rp, ci, rng.normal(size=ci.size))
+            i = A.info()
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        assert i.band_window > 0 and (i.band_strips >= 2) == (case == "strips"), (i.band_window, i.band_strips)
     elif case == "vector":
         A = mk.Matrix.stencil(5, *((300, 200) if size else (40, 30)), scale_seed=4)
         A.set_spmv_kernel(mk.SPMV_VECTOR, 8)
@@ -44,7 +67,7 @@ def _matrix(case, size):
     return A, rng.normal(size=A.nrows)
 
 
-@pytest.mark.parametrize("case", ["sweep", "pattern", "stream", "vsweep", "vector", "split"])
+@pytest.mark.parametrize("case", ["sweep", "pattern", "stream", "vsweep", "vector", "split", "band", "strips"])
 def test_spmv_dot_static_matches_spmv_dot(case):
     for size in (1, 0, 1):                 # large, then smaller, then large again: stale scratch would show
         A, xh = _matrix(case, size)
