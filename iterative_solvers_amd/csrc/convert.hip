@@ -650,8 +650,10 @@ int mk_matrix_from_csr(const SparseMatrixCSR *csr, mk_matrix **A) {
   mk_matrix *M = new mk_matrix();
   M->nrows = csr->nrows; M->ncols = csr->ncolumns; M->nnz = csr->nnz;
   int rc = dev_alloc(&M->rowptr, (size_t)M->nrows + 1);
-  if (rc == MK_OK) rc = dev_alloc(&M->col, (size_t)M->nnz);
-  if (rc == MK_OK) rc = dev_alloc(&M->val, (size_t)M->nnz);
+  // (a few entries of slack: the staging kernels read whole 8- / 16-byte pairs, so the load that holds the last entry may reach
+  // one entry behind it)
+  if (rc == MK_OK) rc = dev_alloc(&M->col, (size_t)M->nnz + 16);
+  if (rc == MK_OK) rc = dev_alloc(&M->val, (size_t)M->nnz + 16);
   if (rc != MK_OK) { free_matrix_buffers(M); delete M; return rc; }
   hipError_t e = hipMemcpyAsync(M->rowptr, csr->row_pointers, sizeof(int) * (M->nrows + 1), hipMemcpyHostToDevice, c.stream);
   if (e == hipSuccess && M->nnz) e = hipMemcpyAsync(M->col, csr->column_indices, sizeof(int) * M->nnz, hipMemcpyHostToDevice, c.stream);
